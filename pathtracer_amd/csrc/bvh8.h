@@ -1,0 +1,59 @@
+// 8-wide quantised BVH: the acceleration structure that stands in for the
+// Embree scene of the reference (rtcCommitScene, src/raytracer.cpp:172-175).
+//
+// Node = 80 bytes = five 16-byte loads per lane.  The eight child boxes are
+// stored as 8-bit offsets on a per-node grid (origin p, power-of-two cell size
+// 2^e per axis), children that are inner nodes sit contiguously from
+// child_base (in slot order), the triangles of all leaf children sit
+// contiguously from tri_base (at most 3 per child, 24 per node).
+//
+// meta[s] of slot s:
+//   empty      : 0
+//   inner node : (1<<5) | (24+s)
+//   leaf       : (unary triangle count: 1->001 2->011 3->111)<<5 | offset from tri_base
+// so "child_bits << (meta & 31)" drops a hit child's bits into a 32-bit hit
+// mask whose top byte indexes inner children and whose low 24 bits index
+// triangles.  Slots are assigned at build time so that visiting inner hits in
+// descending (slot ^ octant_inverse) order is front to back.
+//
+// Triangle = 48 bytes = three 16-byte loads: v0, e1=v1-v0, e2=v2-v0 and the
+// (geomID, primID) pair of the reference's hit record (src/content.cpp:110-111).
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+struct Bvh8Node {
+    float p[3];
+    uint8_t e[3];
+    uint8_t imask;
+    uint32_t child_base;
+    uint32_t tri_base;
+    uint8_t meta[8];
+    uint8_t qlo_x[8], qlo_y[8];
+    uint8_t qlo_z[8], qhi_x[8];
+    uint8_t qhi_y[8], qhi_z[8];
+};
+static_assert(sizeof(Bvh8Node) == 80, "node must be 80 bytes");
+
+struct Bvh8Tri {
+    float v0[3];
+    float e1[3];
+    float e2[3];
+    int32_t obj;
+    int32_t prim;
+    uint32_t pad;
+};
+static_assert(sizeof(Bvh8Tri) == 48, "triangle must be 48 bytes");
+
+struct Bvh8 {
+    std::vector<Bvh8Node> nodes;
+    std::vector<Bvh8Tri> tris;
+    uint32_t max_depth = 0;  // levels of inner nodes on the longest root-to-leaf path
+    float sah_cost = 0.f;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+};
+
+// Builds the BVH over n triangles (verts: 9 floats each; obj/prim: ids copied
+// into the leaf records).  Returns false and fills err for unusable input.
+bool bvh8_build(const float* verts, const int32_t* obj, const int32_t* prim, uint64_t n, Bvh8* out,
+                const char** err);

@@ -1,0 +1,65 @@
+// Wavefront form of udp_renderer::radiance (src/unidirectionalPathTracer.cpp:198-293)
+// for gfx950.
+//
+// The reference evaluates a pixel sample as a recursion tree: every node is
+// one radiance() call, and a node's value enters its parent's through a
+// product of known factors.  Here every node is a task carrying that product
+// (beta) and its pixel; a task adds beta * (local term) to the pixel with a
+// float atomic and emits its children as new tasks.  Tasks of depth d live in
+// queue R[d]; shadow walks (visibility(), cpp:693-790) and the two probe-ray
+// estimators (directLightHit cpp:670-687, directLightingSingleScatter
+// cpp:631-665) have queues of their own.  All queues are three planes of
+// 16-byte words so that a wave reads and writes whole 1 KiB lines.
+//
+//   R  A = org.xyz | pixel     B = dir.xyz | info     C = beta.rgb | key
+//   S  A = from.xyz | pixel    B = to.xyz  | -        C = weight.rgb | -
+//   P  A = org.xyz | pixel     B = dir.xyz | info     C = weight.rgb | medium
+//
+// R.info  = depth | includeEmission<<8 | rayType<<9 | (medium+1)<<12   (medium -1 = global)
+// P.info  = light | kind<<16   (kind 0 = directLightHit, 1 = directLightingSingleScatter)
+#pragma once
+#include "traverse.h"
+
+enum {
+    CNT_QL = 0,   // diffuse hits of the current step (indices into the step)
+    CNT_QS,       // specular hits
+    CNT_QD,       // dielectric / dielectricsss hits
+    CNT_QV,       // segments that scatter
+    CNT_S,        // shadow-walk tasks
+    CNT_P,        // probe tasks
+    CNT_OVERFLOW, // traversal pushes dropped + queue pushes dropped (must stay 0)
+    CNT_R0 = 8,   // CNT_R0 + d: tasks in R[d]
+    CNT_TOTAL = 8 + 64
+};
+
+enum { RAY_CAMERA = 0, RAY_DIFFUSE = 1, RAY_SPECULAR = 2 };  // unidirectionalPathTracer.h:9-11
+
+struct KScene {
+    TraceMem tm;
+    const DMaterial* mats;   // [n_objects + 1], the last one is the global medium
+    const DLight* lights;
+    int32_t n_lights, n_objects;
+    DCamera cam;
+    float wc[3], wr;         // world bound sphere
+};
+
+struct KQueues {
+    float4 *RA, *RB, *RC;    // radiance tasks, depth d at [d*capR, (d+1)*capR)
+    float4 *SA, *SB, *SC;
+    float4 *PA, *PB, *PC;
+    uint2* hits;             // (t bits, triangle) per task of the current step
+    uint32_t *QL, *QS, *QD, *QV;
+    uint32_t capR, capS, capP;
+    uint32_t* cnt;           // CNT_*
+    unsigned long long* rays;  // closest-hit queries issued by shadow and probe kernels
+    float* sum;              // W*H*3 radiance sums
+};
+
+struct KParams {
+    int32_t hsamples, lsamples, td;
+    float me, mr;
+    uint64_t seed;
+    int32_t sample_begin;
+    uint32_t slots_per_sample;  // tilesX*tilesY*64
+    uint32_t tilesX;
+};

@@ -1,0 +1,1264 @@
+// HIP kernels of the radiance loop and the GPU half of the C ABI (include/wapt.h).
+// Queue layout and task encoding: kernels.h.  Traversal: traverse.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh8.h"
+#include "kernels.h"
+#include "wapt_internal.h"
+
+// =============================================================== device helpers
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// Wave-level compaction: the lanes of a wave that have something to emit get
+// consecutive slots from ONE atomic on the queue counter.
+__device__ __forceinline__ uint32_t wave_push(uint32_t* counter, bool pred) {
+    unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0u;
+    uint32_t lane = lane_id();
+    uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, (int)leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ void add_rgb(float* sum, uint32_t pixel, V3 c) {
+    float* p = sum + (size_t)pixel * 3;
+    if (c.x != 0.f) unsafeAtomicAdd(p + 0, c.x);
+    if (c.y != 0.f) unsafeAtomicAdd(p + 1, c.y);
+    if (c.z != 0.f) unsafeAtomicAdd(p + 2, c.z);
+}
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+__device__ __forceinline__ uint32_t make_info(int depth, bool emit, int raytype, int medium) {
+    return (uint32_t)depth | ((uint32_t)emit << 8) | ((uint32_t)raytype << 9) | ((uint32_t)(medium + 1) << 12);
+}
+__device__ __forceinline__ int info_depth(uint32_t i) { return (int)(i & 0xffu); }
+__device__ __forceinline__ bool info_emit(uint32_t i) { return (i >> 8) & 1u; }
+__device__ __forceinline__ int info_raytype(uint32_t i) { return (int)((i >> 9) & 3u); }
+__device__ __forceinline__ int info_medium(uint32_t i) { return (int)(i >> 12) - 1; }
+
+__device__ __forceinline__ const DMaterial& medium_of(const KScene& sc, int medium) {
+    return sc.mats[medium < 0 ? sc.n_objects : medium];
+}
+
+// volumeAttenuation (cpp:407-427)
+__device__ __forceinline__ V3 attenuation(const DMaterial& m, float dist) {
+    if (m.flags & WAPT_MAT_CLEAR) return v3(1.f, 1.f, 1.f);
+    return vexp(v3(-m.st[0] * dist, -m.st[1] * dist, -m.st[2] * dist));
+}
+
+__device__ __forceinline__ bool finite_dir(V3 d) {
+    float l = dot(d, d);
+    return l > 0.25f && l < 4.0f;  // false for NaN
+}
+
+// Emits a radiance task of depth d+1 (all lanes of the wave call this together).
+__device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, bool pred, V3 o, V3 dir, V3 beta,
+                                              uint32_t pixel, uint32_t info, uint32_t key) {
+    pred = pred && finite_dir(dir);
+    uint32_t slot = wave_push(&q.cnt[CNT_R0 + depth_next], pred);
+    if (!pred) return;
+    if (slot >= q.capR) {
+        atomicAdd(&q.cnt[CNT_OVERFLOW], 1u);
+        return;
+    }
+    size_t k = (size_t)depth_next * q.capR + slot;
+    q.RA[k] = make_float4(o.x, o.y, o.z, u2f(pixel));
+    q.RB[k] = make_float4(dir.x, dir.y, dir.z, u2f(info));
+    q.RC[k] = make_float4(beta.x, beta.y, beta.z, u2f(key));
+}
+
+__device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from, V3 to, V3 w, uint32_t pixel) {
+    pred = pred && !(w.x == 0.f && w.y == 0.f && w.z == 0.f);
+    uint32_t slot = wave_push(&q.cnt[CNT_S], pred);
+    if (!pred) return;
+    if (slot >= q.capS) {
+        atomicAdd(&q.cnt[CNT_OVERFLOW], 1u);
+        return;
+    }
+    q.SA[slot] = make_float4(from.x, from.y, from.z, u2f(pixel));
+    q.SB[slot] = make_float4(to.x, to.y, to.z, 0.f);
+    q.SC[slot] = make_float4(w.x, w.y, w.z, 0.f);
+}
+
+__device__ __forceinline__ void push_probe(const KQueues& q, bool pred, V3 o, V3 dir, V3 w, uint32_t pixel,
+                                           uint32_t info, int medium) {
+    pred = pred && finite_dir(dir) && !(w.x == 0.f && w.y == 0.f && w.z == 0.f);
+    uint32_t slot = wave_push(&q.cnt[CNT_P], pred);
+    if (!pred) return;
+    if (slot >= q.capP) {
+        atomicAdd(&q.cnt[CNT_OVERFLOW], 1u);
+        return;
+    }
+    q.PA[slot] = make_float4(o.x, o.y, o.z, u2f(pixel));
+    q.PB[slot] = make_float4(dir.x, dir.y, dir.z, u2f(info));
+    q.PC[slot] = make_float4(w.x, w.y, w.z, u2f((uint32_t)(medium + 1)));
+}
+
+// One task of the current step together with its closest hit.
+struct HitCtx {
+    V3 o, dir, beta;
+    uint32_t pixel, info, key, stream;
+    float t;
+    uint32_t tri;
+    // valid when tri != miss
+    V3 P, N;       // hit point, unit geometric normal
+    int obj;
+    bool entering; // dot(N, D) > 0 with D = -dir (cpp:236)
+};
+
+__device__ __forceinline__ void load_task(const KQueues& q, int depth, uint32_t start, uint32_t i, HitCtx& c) {
+    size_t k = (size_t)depth * q.capR + start + i;
+    float4 a = q.RA[k], b = q.RB[k], cc = q.RC[k];
+    c.o = v3(a.x, a.y, a.z);
+    c.pixel = f2u(a.w);
+    c.dir = v3(b.x, b.y, b.z);
+    c.info = f2u(b.w);
+    c.beta = v3(cc.x, cc.y, cc.z);
+    c.key = f2u(cc.w);
+    c.stream = wapt_stream(c.key, c.pixel);
+}
+
+__device__ __forceinline__ void load_hit(const KScene& sc, const KQueues& q, uint32_t i, HitCtx& c) {
+    uint2 h = q.hits[i];
+    c.t = u2f(h.x);
+    c.tri = h.y;
+    if (c.tri == 0xffffffffu) return;
+    const float4* tp = sc.tm.tris + (size_t)c.tri * 3;
+    float4 a = tp[0], b = tp[1], cc = tp[2];
+    V3 e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, cc.x);
+    c.obj = (int)f2u(cc.y);
+    c.N = normalized(cross(e1, e2));
+    c.P = c.o + c.t * c.dir;  // content.cpp:98-100
+    c.entering = dot(c.N, -c.dir) > 0.0f;
+}
+
+// Roulette thresholds (cpp:252, 256)
+__device__ __forceinline__ float p_surface(int depth) { return 1.0f / (0.125f * (float)depth + 1.0f); }
+__device__ __forceinline__ float p_volume(int depth) { return 1.0f / (0.04f * (float)depth + 1.0f); }
+
+// beta * attenuation(medium0, P0->hit) / pS: the factor on everything the surface event returns (cpp:283-286)
+__device__ __forceinline__ V3 surface_weight(const KScene& sc, const HitCtx& c) {
+    const DMaterial& m0 = medium_of(sc, info_medium(c.info));
+    V3 w = c.beta * attenuation(m0, mag(c.P - c.o));
+    return (1.0f / p_surface(info_depth(c.info))) * w;
+}
+
+#define GRID_LOOP(var, n)                                                                       \
+    for (uint32_t var = blockIdx.x * blockDim.x + threadIdx.x, _n = ((n) + 63u) & ~63u; var < _n; \
+         var += gridDim.x * blockDim.x)
+
+// =============================================================== kernels
+
+__global__ void k_reset(uint32_t* cnt, int r_slot) {
+    uint32_t t = threadIdx.x;
+    if (t <= CNT_P) cnt[t] = 0u;
+    if (r_slot >= 0 && t == 0) cnt[r_slot] = 0u;
+}
+
+// renderTile's sample loop + generateRayForPixel (cpp:122-132, fundamentals.cpp:306-327)
+__global__ __launch_bounds__(WAPT_BLOCK) void k_raygen(KScene sc, KQueues q, KParams p, unsigned long long p0, uint32_t n) {
+    GRID_LOOP(i, n) {
+        bool valid = i < n;
+        unsigned long long path = p0 + i;
+        uint32_t s_local = (uint32_t)(path / p.slots_per_sample);
+        uint32_t r = (uint32_t)(path % p.slots_per_sample);
+        uint32_t tile = r >> 6, within = r & 63u;
+        int px = (int)((tile % p.tilesX) * 8u + (within & 7u));
+        int py = (int)((tile / p.tilesX) * 8u + (within >> 3));
+        valid = valid && px < sc.cam.resI && py < sc.cam.resJ;
+        uint32_t pixel = (uint32_t)(py * sc.cam.resI + px);
+        uint32_t key = wapt_key_root(p.seed, (uint32_t)p.sample_begin + s_local);
+        uint32_t stream = wapt_stream(key, pixel);
+        V3 o, d;
+        camera_ray(sc.cam, px, py, wapt_rand(stream, WAPT_DIM_CAM0), wapt_rand(stream, WAPT_DIM_CAM1), &o, &d);
+        push_radiance(q, 0, valid, o, d, v3(1.f, 1.f, 1.f), pixel, make_info(0, true, RAY_CAMERA, -1), key);
+    }
+}
+
+// traceFAST for every task of the step (content.cpp:91-123)
+__global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int depth, uint32_t start, uint32_t n) {
+    __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
+    uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
+    TraceCount tc = {0, 0, 0, 0};
+    for (uint32_t i = glane; i < n; i += gridDim.x * blockDim.x) {
+        size_t k = (size_t)depth * q.capR + start + i;
+        float4 a = q.RA[k], b = q.RB[k];
+        float tmax = WAPT_TFAR;
+        uint32_t tri = trace_ray<false>(sc.tm, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, tmax,
+                                        &s_stack[threadIdx.x], glane, tc);
+        q.hits[i] = make_uint2(f2u(tmax), tri);
+    }
+    if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
+}
+
+// Head of radiance(): miss handling, roulette, emission, classification (cpp:218-263, 290)
+__global__ __launch_bounds__(WAPT_BLOCK) void k_head(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
+    GRID_LOOP(i, n) {
+        bool valid = i < n;
+        bool toL = false, toS = false, toD = false, toV = false;
+        if (valid) {
+            HitCtx c = {};
+            load_task(q, depth, start, i, c);
+            load_hit(sc, q, i, c);
+            if (c.tri == 0xffffffffu) {
+                // cpp:221-230: the segment to the world sphere is lit through the GLOBAL medium
+                const DMaterial& g = sc.mats[sc.n_objects];
+                V3 rel = c.o - ld3(sc.wc);
+                toV = g.scatters && (mag(rel) < sc.wr);
+            } else {
+                float xs = wapt_rand(c.stream, WAPT_DIM_SURF);
+                if (xs < p_surface(depth)) {
+                    const DMaterial& m = sc.mats[c.obj];
+                    if (info_emit(c.info) && c.obj < sc.n_lights) {
+                        V3 w = surface_weight(sc, c);
+                        add_rgb(q.sum, c.pixel, w * ld3(sc.lights[c.obj].Li));  // primitive.cpp:21-29
+                    }
+                    if (m.flags & WAPT_MAT_DIFFUSE) toL = true;
+                    else if (m.flags & WAPT_MAT_SPECULAR) toS = true;
+                    else if (m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) toD = true;
+                }
+                toV = medium_of(sc, info_medium(c.info)).scatters != 0u;
+            }
+        }
+        uint32_t s;
+        s = wave_push(&q.cnt[CNT_QL], toL);
+        if (toL) q.QL[s] = i;
+        s = wave_push(&q.cnt[CNT_QS], toS);
+        if (toS) q.QS[s] = i;
+        s = wave_push(&q.cnt[CNT_QD], toD);
+        if (toD) q.QD[s] = i;
+        s = wave_push(&q.cnt[CNT_QV], toV);
+        if (toV) q.QV[s] = i;
+    }
+}
+
+// Lambert surfaces: directReflection (cpp:345-381) + indirectReflection (cpp:383-405)
+__global__ __launch_bounds__(WAPT_BLOCK) void k_shade_lambert(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+    uint32_t n = q.cnt[CNT_QL];
+    GRID_LOOP(j, n) {
+        bool valid = j < n;
+        HitCtx c = {};
+        V3 w = v3(0, 0, 0), N1f = v3(0, 0, 1), kd = v3(0, 0, 0);
+        if (valid) {
+            uint32_t i = q.QL[j];
+            load_task(q, depth, start, i, c);
+            load_hit(sc, q, i, c);
+            w = surface_weight(sc, c);
+            N1f = c.entering ? c.N : -c.N;
+            kd = ld3(sc.mats[c.obj].kd);
+        }
+        // next event estimation: one shadow walk per light sample
+        float rls = 1.0f / (float)p.lsamples;
+        for (int l = 0; l < sc.n_lights; l++) {
+            for (int s = 0; s < p.lsamples; s++) {
+                bool emit = false;
+                V3 LP = v3(0, 0, 0), wt = v3(0, 0, 0);
+                if (valid) {
+                    uint32_t dim = WAPT_DIM_NEE + 2u * (uint32_t)(l * p.lsamples + s);
+                    float rpdf;
+                    const DLight& L = sc.lights[l];
+                    if (light_sample(L, c.P, N1f, true, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &LP, &rpdf)) {
+                        V3 Wi = normalized(LP - c.P);
+                        float ndw = dot(Wi, N1f);
+                        if (!(ndw < 0.0f)) {
+                            float sc_ = rls * (1.0f / WAPT_PI) * ndw * rpdf;
+                            wt = sc_ * (w * kd * ld3(L.Li));
+                            emit = true;
+                        }
+                    }
+                }
+                push_shadow(q, emit, c.P, LP, wt, c.pixel);
+            }
+        }
+        // indirect: hsamples uniform hemisphere directions, no emission at the next hit
+        bool deeper = valid && (depth + 1 <= p.td);
+        float rhs = 1.0f / (float)p.hsamples;
+        for (int s = 0; s < p.hsamples; s++) {
+            bool emit = false;
+            V3 Wi = v3(0, 0, 1), b = v3(0, 0, 0);
+            if (deeper) {
+                Wi = hemisphere_uniform(N1f, wapt_rand(c.stream, WAPT_DIM_HEMI + 2u * s),
+                                        wapt_rand(c.stream, WAPT_DIM_HEMI + 2u * s + 1u));
+                float ndw = dot(Wi, N1f);
+                if (!(ndw < 0.0f)) {
+                    b = (rhs * (1.0f / WAPT_PI) * ndw * (2.0f * WAPT_PI)) * (w * kd);
+                    emit = true;
+                }
+            }
+            push_radiance(q, depth + 1, emit, c.P, Wi, b, c.pixel,
+                          make_info(depth + 1, false, RAY_DIFFUSE, info_medium(c.info)),
+                          wapt_key_child(c.key, WAPT_SLOT_HEMI | (uint32_t)s));
+        }
+    }
+}
+
+// Mirror surfaces: the specular branch of reflection() (cpp:329-336)
+__global__ __launch_bounds__(WAPT_BLOCK) void k_shade_specular(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+    uint32_t n = q.cnt[CNT_QS];
+    GRID_LOOP(j, n) {
+        bool emit = false;
+        HitCtx c = {};
+        V3 R = v3(0, 0, 1), b = v3(0, 0, 0);
+        if (j < n) {
+            uint32_t i = q.QS[j];
+            load_task(q, depth, start, i, c);
+            load_hit(sc, q, i, c);
+            if (info_raytype(c.info) != RAY_DIFFUSE && depth + 1 <= p.td) {
+                V3 N1f = c.entering ? c.N : -c.N;
+                R = reflect_dir(-c.dir, N1f);
+                b = surface_weight(sc, c) * ld3(sc.mats[c.obj].ks);
+                emit = true;
+            }
+        }
+        push_radiance(q, depth + 1, emit, c.P, R, b, c.pixel,
+                      make_info(depth + 1, info_emit(c.info), RAY_SPECULAR, info_medium(c.info)),
+                      wapt_key_child(c.key, WAPT_SLOT_SPEC));
+    }
+}
+
+// Dielectric surfaces: the reflect-or-transmit choice of radiance() (cpp:266-280),
+// transmission() (cpp:296-311) and the dielectric branch of reflection() (cpp:329-341)
+__global__ __launch_bounds__(WAPT_BLOCK) void k_shade_dielectric(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+    uint32_t n = q.cnt[CNT_QD];
+    GRID_LOOP(j, n) {
+        bool emit = false;
+        HitCtx c = {};
+        V3 dir = v3(0, 0, 1), b = v3(0, 0, 0);
+        uint32_t info = 0, key = 0;
+        if (j < n) {
+            uint32_t i = q.QD[j];
+            load_task(q, depth, start, i, c);
+            load_hit(sc, q, i, c);
+            const DMaterial& m = sc.mats[c.obj];
+            V3 D = -c.dir;
+            float F;
+            V3 D2 = refract_dir(c.N, D, m.ior, &F);
+            float pR = (1.0f - WAPT_BLEND) * 0.5f + WAPT_BLEND * F;
+            bool transmit = wapt_rand(c.stream, WAPT_DIM_DIEL) < (1.0f - pR);
+            V3 w = surface_weight(sc, c);
+            if (depth + 1 <= p.td) {
+                if (transmit) {
+                    bool kt_nonzero = m.kt[0] != 0.f || m.kt[1] != 0.f || m.kt[2] != 0.f;
+                    if (kt_nonzero && !is_zero(D2)) {
+                        dir = -D2;
+                        b = ((1.0f - F) / (1.0f - pR)) * w;
+                        int medium1 = c.entering ? c.obj : -1;
+                        info = make_info(depth + 1, info_emit(c.info), RAY_CAMERA, medium1);
+                        key = wapt_key_child(c.key, WAPT_SLOT_TRANS);
+                        emit = true;
+                    }
+                } else if (info_raytype(c.info) != RAY_DIFFUSE) {
+                    V3 N1f = c.entering ? c.N : -c.N;
+                    dir = reflect_dir(D, N1f);
+                    b = (F / pR) * (w * ld3(m.ks));
+                    info = make_info(depth + 1, info_emit(c.info), RAY_SPECULAR, info_medium(c.info));
+                    key = wapt_key_child(c.key, WAPT_SLOT_SPEC);
+                    emit = true;
+                }
+            }
+        }
+        push_radiance(q, depth + 1, emit, c.P, dir, b, c.pixel, info, key);
+    }
+}
+
+// volumeScattering (cpp:429-621): ray march along the segment of one task
+__global__ __launch_bounds__(WAPT_BLOCK) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+    uint32_t n = q.cnt[CNT_QV];
+    GRID_LOOP(j, n) {
+        bool valid = j < n;
+        HitCtx c = {};
+        V3 A = v3(0, 0, 0), IBn = v3(0, 0, 1);
+        float len = 0.f, pV = 1.f;
+        bool doVol = false, inside = false;
+        int medium = -1;
+        int rms = 0;
+        if (valid) {
+            uint32_t i = q.QV[j];
+            load_task(q, depth, start, i, c);
+            load_hit(sc, q, i, c);
+            A = c.o;
+            V3 B;
+            if (c.tri == 0xffffffffu) {
+                // exit point on the world sphere: the '+' root (cpp:226-227)
+                V3 rel = c.o - ld3(sc.wc);
+                float m = mag(rel);
+                float s1 = 0.f, s2 = 0.f;
+                solve_quadratic(1.0f, 2.0f * dot(rel, c.dir), m * m - sc.wr * sc.wr, &s1, &s2);
+                B = c.o + s1 * c.dir;
+                medium = -1;
+                doVol = true;
+                pV = 1.0f;
+            } else {
+                B = c.P;
+                medium = info_medium(c.info);
+                inside = !c.entering;  // objID != -1 (cpp:240-248)
+                pV = p_volume(depth);
+                doVol = wapt_rand(c.stream, WAPT_DIM_VOL) < pV;
+            }
+            V3 IB = B - A;
+            len = mag(IB);
+            IBn = (1.0f / len) * IB;
+            rms = (int)(len * p.mr / ((float)depth + 1.0f)) + 1;  // cpp:457
+            if (!(len > 0.f)) rms = 0;
+        }
+        const DMaterial& M = medium_of(sc, medium);
+        V3 ss = ld3(M.ss), st = ld3(M.st);
+        // the inside branch looks for the medium's own surface; the global medium has none
+        bool inside_ok = inside && medium >= 0;
+        int rms_max = rms;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rms_max = max(rms_max, __shfl_xor(rms_max, o));
+        float rrms = rms > 0 ? 1.0f / (float)rms : 0.f;
+        for (int s = 0; s < rms_max; s++) {
+            bool act = valid && s < rms;
+            float x = 0.f, rpdf_x = 0.f;
+            if (act) {
+                float u = wapt_rand(c.stream, WAPT_DIM_MARCH + (uint32_t)s);
+                if (p.me == 0.0f) {  // wa_samplerBeamUniform (sampling.cpp:75-81)
+                    x = u * len;
+                    rpdf_x = len;
+                } else {  // wa_samplerBeamExponentialAttenuation (sampling.cpp:91-100)
+                    float e = 1.0f - expf(-p.me * len);
+                    x = (-1.0f / p.me) * logf(1.0f - e * u);
+                    rpdf_x = 1.0f / ((p.me / e) * expf(-p.me * x));
+                }
+            }
+            V3 S = A + x * IBn;
+            // common factor of everything gathered at S (cpp:611-612) times the scattering albedo and phase
+            V3 cs = (rpdf_x * rrms * WAPT_PHASE) * (c.beta * vexp(v3(-st.x * x, -st.y * x, -st.z * x)) * ss);
+            if (!act) cs = v3(0, 0, 0);
+            float rls = 1.0f / (float)p.lsamples;
+            for (int l = 0; l < sc.n_lights; l++) {
+                const DLight& L = sc.lights[l];
+                if (!__any(act && !inside)) {
+                } else {
+                    // (i) in the open: light sampling and sphere sampling, MIS-weighted (cpp:487-553)
+                    for (int k = 0; k < p.lsamples; k++) {
+                        bool emit = false;
+                        V3 LP = v3(0, 0, 0), wt = v3(0, 0, 0);
+                        if (act && !inside) {
+                            uint32_t dim = WAPT_DIM_VNEE + 2u * (uint32_t)((s * sc.n_lights + l) * p.lsamples + k);
+                            float rpdf;
+                            if (light_sample(L, S, v3(0, 0, 0), false, wapt_rand(c.stream, dim),
+                                             wapt_rand(c.stream, dim + 1), &LP, &rpdf)) {
+                                float pdf = 1.0f / rpdf;
+                                float mis = pdf / (pdf + WAPT_MIS_CONST);
+                                if (rpdf == 0.0f) mis = 1.0f;
+                                wt = (rpdf * mis * rls) * (cs * ld3(L.Li));
+                                emit = true;
+                            }
+                        }
+                        push_shadow(q, emit, S, LP, wt, c.pixel);
+                    }
+                    {
+                        uint32_t dim = WAPT_DIM_VPROBE + 2u * (uint32_t)(s * sc.n_lights + l);
+                        V3 dir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
+                        push_probe(q, act && !inside, S, dir, (4.0f * WAPT_PI) * cs, c.pixel, (uint32_t)l, medium);
+                    }
+                }
+                if (__any(act && inside_ok)) {
+                    // (ii) inside an object: 16 refracted connections per light (cpp:560-583)
+                    V3 toL = normalized(ld3(L.centre) - S);
+                    for (int k = 0; k < 16; k++) {
+                        uint32_t dim = WAPT_DIM_VSINGLE + 2u * (uint32_t)((s * sc.n_lights + l) * 16 + k);
+                        float rpdf = 0.f;
+                        V3 dir = v3(0, 0, 1);
+                        if (act && inside_ok)
+                            dir = sphere_biased3(toL, 1.5f, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &rpdf);
+                        push_probe(q, act && inside_ok, S, dir, ((1.0f / 16.0f) * rpdf) * cs, c.pixel,
+                                   (uint32_t)l | (1u << 16), medium);
+                    }
+                }
+            }
+            // (iii) indirect: one uniform direction, no emission at the next hit (cpp:587-609)
+            {
+                bool emit = act && doVol && (depth + 1 <= p.td);
+                uint32_t dim = WAPT_DIM_VCHILD + 2u * (uint32_t)s;
+                V3 dir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
+                push_radiance(q, depth + 1, emit, S, dir, ((4.0f * WAPT_PI) / pV) * cs, c.pixel,
+                              make_info(depth + 1, false, RAY_CAMERA, medium),
+                              wapt_key_child(c.key, WAPT_SLOT_VOL | (uint32_t)s));
+            }
+        }
+    }
+}
+
+// visibility() (cpp:693-790): walk from A to B through every surface in between
+__global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
+    __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
+    uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = q.cnt[CNT_S];
+    TraceCount tc = {0, 0, 0, 0};
+    uint32_t rays = 0;
+    const int global_m = sc.n_objects;
+    for (uint32_t i = glane; i < n; i += gridDim.x * blockDim.x) {
+        float4 a = q.SA[i], b = q.SB[i], w4 = q.SC[i];
+        V3 A = v3(a.x, a.y, a.z), B = v3(b.x, b.y, b.z);
+        uint32_t pixel = f2u(a.w);
+        V3 AB = B - A;
+        float ABl = mag(AB);
+        V3 ABn = (1.0f / ABl) * AB;
+        V3 V = v3(1.f, 1.f, 1.f);
+        V3 P0 = A;
+        float d = 0.f;
+        int cur = global_m;
+        bool lit = false;
+        if (!(ABl > 0.f)) continue;
+        for (int it = 0; it < 4096; it++) {
+            float tmax = WAPT_TFAR;
+            uint32_t tri = trace_ray<false>(sc.tm, P0, ABn, WAPT_TRACE_BIAS, tmax, &s_stack[threadIdx.x], glane, tc);
+            rays++;
+            V3 P1;
+            bool entering = false, opaque = false;
+            int obj = -1;
+            V3 hp = P0 + tmax * ABn;
+            if (tri != 0xffffffffu) d += mag(hp - P0);
+            else d = 2.0f * ABl;
+            if (d <= ABl + WAPT_TRACE_BIAS) {
+                const float4* tp = sc.tm.tris + (size_t)tri * 3;
+                float4 ta = tp[0], tb = tp[1], tcx = tp[2];
+                V3 N = normalized(cross(v3(ta.w, tb.x, tb.y), v3(tb.z, tb.w, tcx.x)));
+                obj = (int)f2u(tcx.y);
+                const DMaterial& m = sc.mats[obj];
+                P1 = hp;
+                entering = dot(ABn, N) < 0.0f;
+                opaque = (m.flags & WAPT_MAT_OPAQUE) != 0u;
+                if (entering) {
+                    cur = global_m;
+                    // glass blocks shadow walks outright (cpp:757-759)
+                    if ((m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) && m.ior > 1.0f) break;
+                } else {
+                    cur = obj;
+                }
+            } else {
+                P1 = B;
+                d = ABl;
+            }
+            V = V * attenuation(sc.mats[cur], mag(P1 - P0));
+            if (d >= ABl - WAPT_TRACE_BIAS) {
+                lit = true;
+                break;
+            }
+            if (opaque) break;
+            if (V.x < WAPT_LOW_VIS && V.y < WAPT_LOW_VIS && V.z < WAPT_LOW_VIS) break;
+            P0 = P1;
+            cur = entering ? obj : global_m;
+        }
+        if (lit) add_rgb(q.sum, pixel, v3(w4.x, w4.y, w4.z) * V);
+    }
+    rays = wave_sum(rays);
+    if (lane_id() == 0 && rays) atomicAdd(q.rays, (unsigned long long)rays);
+    if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
+}
+
+// directLightHit (cpp:670-687) and directLightingSingleScatter (cpp:631-665)
+__global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
+    __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
+    uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = q.cnt[CNT_P];
+    TraceCount tc = {0, 0, 0, 0};
+    uint32_t rays = 0;
+    for (uint32_t i = glane; i < n; i += gridDim.x * blockDim.x) {
+        float4 a = q.PA[i], b = q.PB[i], w4 = q.PC[i];
+        V3 S = v3(a.x, a.y, a.z), dir = v3(b.x, b.y, b.z), w = v3(w4.x, w4.y, w4.z);
+        uint32_t pixel = f2u(a.w), info = f2u(b.w);
+        int light = (int)(info & 0xffffu);
+        int kind = (int)(info >> 16);
+        int medium = (int)f2u(w4.w) - 1;
+        const DMaterial& M = medium_of(sc, medium);
+        float tmax = WAPT_TFAR;
+        uint32_t tri = trace_ray<false>(sc.tm, S, dir, WAPT_TRACE_BIAS, tmax, &s_stack[threadIdx.x], glane, tc);
+        rays++;
+        if (tri == 0xffffffffu) continue;
+        const float4* tp = sc.tm.tris + (size_t)tri * 3;
+        float4 ta = tp[0], tb = tp[1], tcx = tp[2];
+        int obj = (int)f2u(tcx.y);
+        V3 hp = S + tmax * dir;
+        const DLight& L = sc.lights[light];
+        if (kind == 0) {
+            if (obj != light) continue;
+            V3 att = attenuation(M, mag(hp - S));
+            float alt = light_pdf(L, hp, S);
+            float mis = WAPT_MIS_CONST / (WAPT_MIS_CONST + alt);
+            if (mis != mis) mis = 1.0f;
+            add_rgb(q.sum, pixel, mis * (w * ld3(L.Li) * att));
+        } else {
+            if (obj != medium) continue;
+            V3 N = normalized(cross(v3(ta.w, tb.x, tb.y), v3(tb.z, tb.w, tcx.x)));
+            float F;
+            V3 D1 = refract_dir(N, -dir, M.ior, &F);
+            if (is_zero(D1)) continue;
+            V3 dir1 = -D1;
+            if (!finite_dir(dir1)) continue;
+            float tmax1 = WAPT_TFAR;
+            uint32_t tri1 = trace_ray<false>(sc.tm, hp, dir1, WAPT_TRACE_BIAS, tmax1, &s_stack[threadIdx.x], glane, tc);
+            rays++;
+            if (tri1 == 0xffffffffu) continue;
+            int obj1 = (int)f2u(sc.tm.tris[(size_t)tri1 * 3 + 2].y);
+            if (obj1 != light) continue;
+            V3 hp1 = hp + tmax1 * dir1;
+            V3 att = attenuation(sc.mats[sc.n_objects], mag(hp1 - hp)) * attenuation(M, mag(hp - S));
+            add_rgb(q.sum, pixel, (1.0f - F) * (w * ld3(L.Li) * att));
+        }
+    }
+    rays = wave_sum(rays);
+    if (lane_id() == 0 && rays) atomicAdd(q.rays, (unsigned long long)rays);
+    if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
+}
+
+// Batch closest-hit for wapt_intersect*
+template <bool COUNT>
+__global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const float4* rays, uint32_t n, float* hits,
+                                                          unsigned long long* counters) {
+    __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
+    uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
+    TraceCount tc = {0, 0, 0, 0};
+    for (uint32_t i = glane; i < n; i += gridDim.x * blockDim.x) {
+        float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
+        float tmax = b.w;
+        uint32_t tri = trace_ray<COUNT>(tm, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, &s_stack[threadIdx.x], glane, tc);
+        float* h = hits + 6 * (size_t)i;
+        if (tri == 0xffffffffu) {
+            h[0] = tmax;
+            h[1] = u2f(0xffffffffu);
+            h[2] = u2f(0xffffffffu);
+            h[3] = h[4] = h[5] = 0.f;
+        } else {
+            const float4* tp = tm.tris + (size_t)tri * 3;
+            float4 ta = tp[0], tb = tp[1], tcx = tp[2];
+            V3 Ng = cross(v3(ta.w, tb.x, tb.y), v3(tb.z, tb.w, tcx.x));
+            h[0] = tmax;
+            h[1] = tcx.z;  // prim
+            h[2] = tcx.y;  // obj
+            h[3] = Ng.x;
+            h[4] = Ng.y;
+            h[5] = Ng.z;
+        }
+    }
+    if (COUNT) {
+        uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.tris), c = wave_sum(tc.spills);
+        if (lane_id() == 0) {
+            atomicAdd(&counters[0], (unsigned long long)a);
+            atomicAdd(&counters[1], (unsigned long long)b);
+            atomicAdd(&counters[2], (unsigned long long)c);
+        }
+    }
+    uint32_t ov = wave_sum(tc.overflow);
+    if (lane_id() == 0 && ov) atomicAdd(&counters[3], (unsigned long long)ov);
+}
+
+// =============================================================== host side
+
+#define HIPCHK(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (call);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return wapt_fail(WAPT_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+
+struct wapt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Bvh8 bvh_info_only;  // nodes/tris vectors are released after upload; counts kept below
+    uint64_t n_nodes = 0, n_tris = 0;
+    uint32_t bvh_depth = 0;
+    float sah = 0.f;
+    KScene ks;
+    // owned device memory
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_spill = nullptr;
+    uint32_t* d_cnt = nullptr;
+    unsigned long long* d_rays = nullptr;
+    uint32_t* h_cnt = nullptr;  // pinned
+    KQueues kq;
+    void* d_queue_block = nullptr;
+    size_t queue_bytes = 0;
+    int queue_depths = 0;
+    uint32_t grid = 0;
+    uint32_t capR = 0, capS = 0, capP = 0;
+    bool has_scatter = false, has_inside = false;
+    float max_segment = 0.f;
+    int n_lights = 0;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+uint32_t env_u32(const char* name, uint32_t def) {
+    const char* v = getenv(name);
+    if (!v || !*v) return def;
+    long long x = atoll(v);
+    return x > 0 ? (uint32_t)x : def;
+}
+
+DMaterial to_device(const wapt_material& m) {
+    DMaterial d;
+    memset(&d, 0, sizeof(d));
+    memcpy(d.kd, m.kd, 12);
+    memcpy(d.ks, m.ks, 12);
+    memcpy(d.kt, m.kt, 12);
+    memcpy(d.ss, m.ss, 12);
+    memcpy(d.st, m.st, 12);
+    d.ior = m.ior;
+    d.flags = m.flags;
+    bool ss0 = m.ss[0] == 0.f && m.ss[1] == 0.f && m.ss[2] == 0.f;
+    d.scatters = (!(m.flags & WAPT_MAT_CLEAR) && !ss0) ? 1u : 0u;
+    return d;
+}
+
+void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// wa_areaLight / wa_sphereLight constructors (lights.cpp:24-34, 136-143)
+DLight to_device(const wapt_light& l) {
+    DLight d;
+    memset(&d, 0, sizeof(d));
+    d.type = l.type;
+    memcpy(d.P, l.P, 12);
+    const double pi = 3.1415926535;
+    if (l.type == 0) {
+        memcpy(d.U, l.U, 12);
+        memcpy(d.V, l.V, 12);
+        float n[3];
+        cross3(l.U, l.V, n);
+        float m = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        for (int a = 0; a < 3; a++) d.N[a] = n[a] / m;
+        d.area = sqrtf(l.U[0] * l.U[0] + l.U[1] * l.U[1] + l.U[2] * l.U[2]) *
+                 sqrtf(l.V[0] * l.V[0] + l.V[1] * l.V[1] + l.V[2] * l.V[2]);
+        for (int a = 0; a < 3; a++) {
+            float irr = (float)(0.5 * l.power[a]) / d.area;
+            d.Li[a] = (float)(irr / pi);
+            d.centre[a] = l.P[a] + 0.5f * (l.U[a] + l.V[a]);
+        }
+    } else {
+        d.radius = l.radius;
+        for (int a = 0; a < 3; a++) {
+            float irr = (float)(l.power[a] / (4.0 * pi * (double)l.radius * (double)l.radius));
+            d.Li[a] = (float)(irr / pi);
+            d.centre[a] = l.P[a];
+        }
+    }
+    return d;
+}
+
+// wa_camera constructor + setResolution (fundamentals.cpp:227-263)
+DCamera to_device(const wapt_camera& c) {
+    DCamera d;
+    memset(&d, 0, sizeof(d));
+    d.type = c.type;
+    d.resI = c.resI;
+    d.resJ = c.resJ;
+    memcpy(d.P, c.P, 12);
+    memcpy(d.D, c.D, 12);
+    float side[3], up[3];
+    cross3(c.D, c.up, side);
+    float m = sqrtf(side[0] * side[0] + side[1] * side[1] + side[2] * side[2]);
+    for (int a = 0; a < 3; a++) side[a] /= m;
+    cross3(side, c.D, up);
+    const double pi = 3.1415926535;
+    float sensorDist = (float)(0.5 * c.sensor_width / tan(0.5 * c.fov_deg * (pi / 180.0)));
+    float aspect = (float)c.resJ / (float)c.resI;
+    for (int a = 0; a < 3; a++) {
+        d.side[a] = side[a];
+        d.up[a] = up[a];
+        d.sensorOrigin[a] = (float)(c.P[a] + sensorDist * c.D[a] - 0.5 * c.sensor_width * (side[a] + aspect * up[a]));
+    }
+    d.pixelWidth = c.sensor_width / (float)c.resI;
+    d.sensorWidth = c.sensor_width;
+    return d;
+}
+
+int validate_desc(const wapt_scene_desc* d) {
+    if (!d) return wapt_fail(WAPT_E_INVALID, "null scene description");
+    if (d->n_tris == 0 || !d->tri_verts || !d->tri_obj) return wapt_fail(WAPT_E_INVALID, "scene has no triangles");
+    if (d->n_objects <= 0 || !d->materials) return wapt_fail(WAPT_E_INVALID, "scene has no objects");
+    if (d->n_lights < 0 || d->n_lights > d->n_objects || (d->n_lights > 0 && !d->lights))
+        return wapt_fail(WAPT_E_INVALID, "bad light table");
+    if (d->n_lights > 0xffff) return wapt_fail(WAPT_E_LIMIT, "more than 65535 lights");
+    if (d->n_objects >= (1 << 20) - 1) return wapt_fail(WAPT_E_LIMIT, "more than 2^20-2 objects");
+    if (d->camera.resI <= 0 || d->camera.resJ <= 0) return wapt_fail(WAPT_E_INVALID, "bad resolution");
+    if ((uint64_t)d->camera.resI * (uint64_t)d->camera.resJ >= (1ull << 30))
+        return wapt_fail(WAPT_E_LIMIT, "image larger than 2^30 pixels");
+    for (uint64_t t = 0; t < d->n_tris; t++)
+        if (d->tri_obj[t] < 0 || d->tri_obj[t] >= d->n_objects)
+            return wapt_fail(WAPT_E_INVALID, "triangle refers to an object outside the material table");
+    if (!(d->world_radius > 0.f)) return wapt_fail(WAPT_E_INVALID, "world radius must be positive");
+    return WAPT_OK;
+}
+
+}  // namespace
+
+extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wapt_scene** out) {
+    if (!out) return wapt_fail(WAPT_E_INVALID, "null output");
+    *out = nullptr;
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return wapt_fail(WAPT_E_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (device < 0 || device >= ndev) return wapt_fail(WAPT_E_INVALID, "device index out of range");
+
+    Bvh8 bvh;
+    const char* err = nullptr;
+    if (!bvh8_build(desc->tri_verts, desc->tri_obj, desc->tri_prim, desc->n_tris, &bvh, &err))
+        return wapt_fail(WAPT_E_INVALID, std::string("BVH build: ") + err);
+    if (bvh.max_depth > WAPT_STACK_CAP)
+        return wapt_fail(WAPT_E_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(bvh.max_depth) + ")");
+
+    HIPCHK(hipSetDevice(device));
+    auto s = new wapt_scene();
+    s->device = device;
+    auto bail = [&](int code) {
+        wapt_scene_destroy(s);
+        return code;
+    };
+#define HIPCHK_S(call)                                                                                       \
+    do {                                                                                                     \
+        hipError_t _e = (call);                                                                              \
+        if (_e != hipSuccess) return bail(wapt_fail(WAPT_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e))); \
+    } while (0)
+
+    HIPCHK_S(hipStreamCreate(&s->stream));
+    s->n_nodes = bvh.nodes.size();
+    s->n_tris = bvh.tris.size();
+    s->bvh_depth = bvh.max_depth;
+    s->sah = bvh.sah_cost;
+    HIPCHK_S(hipMalloc(&s->d_nodes, bvh.nodes.size() * sizeof(Bvh8Node)));
+    HIPCHK_S(hipMalloc(&s->d_tris, bvh.tris.size() * sizeof(Bvh8Tri)));
+    HIPCHK_S(hipMemcpy(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice));
+    HIPCHK_S(hipMemcpy(s->d_tris, bvh.tris.data(), bvh.tris.size() * sizeof(Bvh8Tri), hipMemcpyHostToDevice));
+
+    std::vector<DMaterial> mats((size_t)desc->n_objects + 1);
+    for (int i = 0; i < desc->n_objects; i++) mats[i] = to_device(desc->materials[i]);
+    mats[desc->n_objects] = to_device(desc->global_medium);
+    s->has_scatter = false;
+    s->has_inside = false;
+    for (int i = 0; i <= desc->n_objects; i++) {
+        if (mats[i].scatters) {
+            s->has_scatter = true;
+            if (i < desc->n_objects) s->has_inside = true;
+        }
+    }
+    HIPCHK_S(hipMalloc(&s->d_mats, mats.size() * sizeof(DMaterial)));
+    HIPCHK_S(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
+    std::vector<DLight> lights((size_t)std::max(desc->n_lights, 1));
+    for (int i = 0; i < desc->n_lights; i++) lights[i] = to_device(desc->lights[i]);
+    HIPCHK_S(hipMalloc(&s->d_lights, lights.size() * sizeof(DLight)));
+    HIPCHK_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    s->n_lights = desc->n_lights;
+
+    // longest possible segment: everything lives inside the ball around the world
+    // centre that holds the world sphere, the geometry and the camera
+    {
+        double rb = desc->world_radius;
+        for (int cx = 0; cx < 8; cx++) {
+            double dx = ((cx & 1) ? bvh.hi[0] : bvh.lo[0]) - desc->world_center[0];
+            double dy = ((cx & 2) ? bvh.hi[1] : bvh.lo[1]) - desc->world_center[1];
+            double dz = ((cx & 4) ? bvh.hi[2] : bvh.lo[2]) - desc->world_center[2];
+            rb = std::max(rb, std::sqrt(dx * dx + dy * dy + dz * dz));
+        }
+        double dx = desc->camera.P[0] - desc->world_center[0], dy = desc->camera.P[1] - desc->world_center[1],
+               dz = desc->camera.P[2] - desc->world_center[2];
+        rb = std::max(rb, std::sqrt(dx * dx + dy * dy + dz * dz));
+        s->max_segment = (float)(2.0 * rb * 1.001);
+    }
+
+    hipDeviceProp_t prop;
+    HIPCHK_S(hipGetDeviceProperties(&prop, device));
+    uint32_t cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
+    s->grid = cus * env_u32("WAPT_BLOCKS_PER_CU", 6);
+    size_t spill_entries = (size_t)(WAPT_STACK_CAP - WAPT_LDS_STACK) * s->grid * WAPT_BLOCK;
+    HIPCHK_S(hipMalloc(&s->d_spill, spill_entries * sizeof(uint2)));
+    HIPCHK_S(hipMalloc((void**)&s->d_cnt, CNT_TOTAL * sizeof(uint32_t)));
+    HIPCHK_S(hipMemset(s->d_cnt, 0, CNT_TOTAL * sizeof(uint32_t)));
+    HIPCHK_S(hipMalloc((void**)&s->d_rays, 4 * sizeof(unsigned long long)));
+    HIPCHK_S(hipMemset(s->d_rays, 0, 4 * sizeof(unsigned long long)));
+    HIPCHK_S(hipHostMalloc((void**)&s->h_cnt, CNT_TOTAL * sizeof(uint32_t) + 64));
+
+    memset(&s->ks, 0, sizeof(s->ks));
+    s->ks.tm.nodes = (const uint4*)s->d_nodes;
+    s->ks.tm.tris = (const float4*)s->d_tris;
+    s->ks.tm.spill = (uint2*)s->d_spill;
+    s->ks.tm.spill_stride = s->grid * WAPT_BLOCK;
+    s->ks.mats = (const DMaterial*)s->d_mats;
+    s->ks.lights = (const DLight*)s->d_lights;
+    s->ks.n_lights = desc->n_lights;
+    s->ks.n_objects = desc->n_objects;
+    s->ks.cam = to_device(desc->camera);
+    memcpy(s->ks.wc, desc->world_center, 12);
+    s->ks.wr = desc->world_radius;
+    memset(&s->kq, 0, sizeof(s->kq));
+    HIPCHK_S(hipDeviceSynchronize());
+    *out = s;
+    return WAPT_OK;
+#undef HIPCHK_S
+}
+
+extern "C" void wapt_scene_destroy(wapt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+    (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_tris);
+    (void)hipFree(s->d_mats);
+    (void)hipFree(s->d_lights);
+    (void)hipFree(s->d_spill);
+    (void)hipFree(s->d_cnt);
+    (void)hipFree(s->d_rays);
+    (void)hipFree(s->d_queue_block);
+    if (s->h_cnt) (void)hipHostFree(s->h_cnt);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" int wapt_scene_bvh_info(const wapt_scene* s, wapt_bvh_info* o) {
+    if (!s || !o) return wapt_fail(WAPT_E_INVALID, "null argument");
+    o->n_nodes = s->n_nodes;
+    o->n_tris = s->n_tris;
+    o->node_size = sizeof(Bvh8Node);
+    o->tri_size = sizeof(Bvh8Tri);
+    o->node_bytes = s->n_nodes * sizeof(Bvh8Node);
+    o->tri_bytes = s->n_tris * sizeof(Bvh8Tri);
+    o->max_depth = s->bvh_depth;
+    o->sah_cost = s->sah;
+    return WAPT_OK;
+}
+
+namespace {
+
+// (Re)allocates the work queues for a trace depth.
+int ensure_queues(wapt_scene* s, int td) {
+    int depths = td + 1;
+    if (s->d_queue_block && s->queue_depths >= depths) return WAPT_OK;
+    if (s->d_queue_block) {
+        HIPCHK(hipFree(s->d_queue_block));
+        s->d_queue_block = nullptr;
+    }
+    uint32_t capR = env_u32("WAPT_RAD_CAP", 1u << 22);
+    capR = std::max(capR, 64u * 64u);
+    capR &= ~63u;
+    uint32_t capS = env_u32("WAPT_SHADOW_CAP", s->has_scatter ? (1u << 24) : capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
+    uint32_t capP = env_u32("WAPT_PROBE_CAP", s->has_scatter ? (1u << 24) : 64u);
+    size_t bytes = 0;
+    auto take = [&](size_t b) {
+        size_t off = bytes;
+        bytes += (b + 255) & ~(size_t)255;
+        return off;
+    };
+    size_t oRA = take((size_t)depths * capR * 16), oRB = take((size_t)depths * capR * 16), oRC = take((size_t)depths * capR * 16);
+    size_t oSA = take((size_t)capS * 16), oSB = take((size_t)capS * 16), oSC = take((size_t)capS * 16);
+    size_t oPA = take((size_t)capP * 16), oPB = take((size_t)capP * 16), oPC = take((size_t)capP * 16);
+    size_t oH = take((size_t)capR * 8);
+    size_t oQL = take((size_t)capR * 4), oQS = take((size_t)capR * 4), oQD = take((size_t)capR * 4), oQV = take((size_t)capR * 4);
+    HIPCHK(hipMalloc(&s->d_queue_block, bytes));
+    char* b = (char*)s->d_queue_block;
+    KQueues& q = s->kq;
+    q.RA = (float4*)(b + oRA);
+    q.RB = (float4*)(b + oRB);
+    q.RC = (float4*)(b + oRC);
+    q.SA = (float4*)(b + oSA);
+    q.SB = (float4*)(b + oSB);
+    q.SC = (float4*)(b + oSC);
+    q.PA = (float4*)(b + oPA);
+    q.PB = (float4*)(b + oPB);
+    q.PC = (float4*)(b + oPC);
+    q.hits = (uint2*)(b + oH);
+    q.QL = (uint32_t*)(b + oQL);
+    q.QS = (uint32_t*)(b + oQS);
+    q.QD = (uint32_t*)(b + oQD);
+    q.QV = (uint32_t*)(b + oQV);
+    q.capR = capR;
+    q.capS = capS;
+    q.capP = capP;
+    q.cnt = s->d_cnt;
+    q.rays = s->d_rays;
+    s->capR = capR;
+    s->capS = capS;
+    s->capP = capP;
+    s->queue_bytes = bytes;
+    s->queue_depths = depths;
+    return WAPT_OK;
+}
+
+struct Timer {
+    wapt_scene* s;
+    bool on;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> recs;
+    size_t next = 0;
+    hipEvent_t get() {
+        if (next == s->ev_pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            s->ev_pool.push_back(e);
+        }
+        return s->ev_pool[next++];
+    }
+    template <class F>
+    void run(int family, F&& f) {
+        if (!on) {
+            f();
+            return;
+        }
+        hipEvent_t a = get(), b = get();
+        (void)hipEventRecord(a, s->stream);
+        f();
+        (void)hipEventRecord(b, s->stream);
+        recs.push_back({family, {a, b}});
+    }
+};
+
+enum { FAM_RAYGEN, FAM_TRACE, FAM_HEAD, FAM_SHADE, FAM_VOLUME, FAM_SHADOW, FAM_PROBE, FAM_N };
+
+}  // namespace
+
+extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* prm, float* d_sum, wapt_stats* stats) {
+    if (!s || !prm || !d_sum) return wapt_fail(WAPT_E_INVALID, "null argument");
+    if (prm->psamples <= 0 || prm->hsamples <= 0 || prm->lsamples <= 0)
+        return wapt_fail(WAPT_E_INVALID, "psamples, hsamples and lsamples must be positive");
+    if (prm->max_depth < 0 || prm->max_depth > 62) return wapt_fail(WAPT_E_LIMIT, "max_depth must be in [0, 62]");
+    if (prm->sample_begin < 0 || prm->sample_count < 0) return wapt_fail(WAPT_E_INVALID, "bad sample range");
+    if (!(prm->mr >= 0.f) || !(prm->me >= 0.f)) return wapt_fail(WAPT_E_INVALID, "mr and me must be >= 0");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_queues(s, prm->max_depth);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+
+    const int td = prm->max_depth;
+    const int W = s->ks.cam.resI, H = s->ks.cam.resJ;
+    KParams kp;
+    memset(&kp, 0, sizeof(kp));
+    kp.hsamples = prm->hsamples;
+    kp.lsamples = prm->lsamples;
+    kp.td = td;
+    kp.me = prm->me;
+    kp.mr = prm->mr;
+    kp.seed = prm->seed;
+    kp.sample_begin = prm->sample_begin;
+    kp.tilesX = (uint32_t)((W + 7) / 8);
+    kp.slots_per_sample = kp.tilesX * (uint32_t)((H + 7) / 8) * 64u;
+    KQueues q = s->kq;
+    q.sum = d_sum;
+    const KScene& ks = s->ks;
+    hipStream_t st = s->stream;
+    const dim3 grid(s->grid), block(WAPT_BLOCK);
+
+    // worst-case fan-out of one task of depth d (sizes the chunk taken from R[d])
+    const int L = s->n_lights;
+    auto rms_max = [&](int d) -> uint64_t {
+        if (!s->has_scatter) return 0;
+        return (uint64_t)((double)s->max_segment * prm->mr / (d + 1.0)) + 1;
+    };
+    auto chunk_for = [&](int d) -> uint32_t {
+        uint64_t r = rms_max(d);
+        uint64_t kids = (uint64_t)std::max(prm->hsamples, 1) + r;
+        uint64_t shadows = (uint64_t)L * prm->lsamples * (1 + r);
+        uint64_t probes = r * (uint64_t)L * (s->has_inside ? 16 : 1);
+        uint64_t c = s->capR;
+        if (d < td) c = std::min<uint64_t>(c, s->capR / kids);
+        if (shadows) c = std::min<uint64_t>(c, s->capS / shadows);
+        if (probes) c = std::min<uint64_t>(c, s->capP / probes);
+        return (uint32_t)c;
+    };
+    for (int d = 0; d <= td; d++)
+        if (chunk_for(d) == 0)
+            return wapt_fail(WAPT_E_LIMIT, "queue capacity too small for the fan-out of this scene and these settings");
+
+    Timer tm{s, prm->profile != 0, {}, 0};
+    std::vector<uint32_t> have((size_t)td + 2, 0u);
+    const unsigned long long total = (unsigned long long)kp.slots_per_sample * (unsigned long long)prm->sample_count;
+    unsigned long long issued = 0;
+    uint64_t rays_trace = 0, n_trace_launches = 0, n_shadow_launches = 0;
+    HIPCHK(hipMemsetAsync(s->d_rays, 0, 4 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, CNT_OVERFLOW);
+
+    for (;;) {
+        int d = -1;
+        for (int k = td; k >= 0; k--)
+            if (have[k]) {
+                d = k;
+                break;
+            }
+        if (d < 0) {
+            if (issued >= total) break;
+            uint32_t n = (uint32_t)std::min<unsigned long long>(s->capR, total - issued);
+            hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, CNT_R0);
+            tm.run(FAM_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, grid, block, 0, st, ks, q, kp, issued, n); });
+            issued += n;
+            HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            have[0] = std::min(s->h_cnt[CNT_R0], s->capR);
+            continue;
+        }
+        uint32_t n = std::min(have[d], chunk_for(d));
+        uint32_t start = have[d] - n;
+        have[d] = start;
+        hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, d < td ? CNT_R0 + d + 1 : -1);
+        tm.run(FAM_TRACE, [&] { hipLaunchKernelGGL(k_trace, grid, block, 0, st, ks, q, d, start, n); });
+        rays_trace += n;
+        n_trace_launches++;
+        tm.run(FAM_HEAD, [&] { hipLaunchKernelGGL(k_head, grid, block, 0, st, ks, q, kp, d, start, n); });
+        tm.run(FAM_SHADE, [&] {
+            hipLaunchKernelGGL(k_shade_lambert, grid, block, 0, st, ks, q, kp, d, start);
+            hipLaunchKernelGGL(k_shade_specular, grid, block, 0, st, ks, q, kp, d, start);
+            hipLaunchKernelGGL(k_shade_dielectric, grid, block, 0, st, ks, q, kp, d, start);
+        });
+        if (s->has_scatter) {
+            tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_volume, grid, block, 0, st, ks, q, kp, d, start); });
+            tm.run(FAM_PROBE, [&] { hipLaunchKernelGGL(k_probe, grid, block, 0, st, ks, q); });
+        }
+        tm.run(FAM_SHADOW, [&] { hipLaunchKernelGGL(k_shadow, grid, block, 0, st, ks, q); });
+        n_shadow_launches++;
+        if (d < td) {
+            HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            have[d + 1] = std::min(s->h_cnt[CNT_R0 + d + 1], s->capR);
+        }
+    }
+    unsigned long long h_rays[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_rays, s->d_rays, sizeof(h_rays), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    auto t1 = std::chrono::steady_clock::now();
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->paths = (uint64_t)W * H * (uint64_t)prm->sample_count;
+        stats->rays = rays_trace + h_rays[0];
+        stats->stack_overflows = s->h_cnt[CNT_OVERFLOW];
+        stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+        stats->n_trace_launches = n_trace_launches;
+        stats->n_trace_rays = rays_trace;
+        stats->n_shadow_launches = n_shadow_launches;
+        stats->n_shadow_rays = h_rays[0];
+        if (tm.on) {
+            double ms[FAM_N] = {0};
+            for (auto& r : tm.recs) {
+                float e = 0.f;
+                (void)hipEventElapsedTime(&e, r.second.first, r.second.second);
+                ms[r.first] += e;
+            }
+            stats->ms_raygen = ms[FAM_RAYGEN];
+            stats->ms_trace = ms[FAM_TRACE];
+            stats->ms_head = ms[FAM_HEAD];
+            stats->ms_shade = ms[FAM_SHADE];
+            stats->ms_volume = ms[FAM_VOLUME];
+            stats->ms_shadow = ms[FAM_SHADOW];
+            stats->ms_probe = ms[FAM_PROBE];
+        }
+    }
+    if (s->h_cnt[CNT_OVERFLOW])
+        return wapt_fail(WAPT_E_LIMIT, "work dropped: " + std::to_string(s->h_cnt[CNT_OVERFLOW]) + " stack or queue overflows");
+    return WAPT_OK;
+}
+
+__global__ void k_resolve(const float* sum, float* out, size_t n, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sum[i] * scale;
+}
+
+extern "C" int wapt_render(wapt_scene* s, const wapt_render_params* prm, float* fb, wapt_stats* stats) {
+    if (!s || !prm || !fb) return wapt_fail(WAPT_E_INVALID, "null argument");
+    if (prm->sample_begin != 0 || prm->sample_count != prm->psamples)
+        return wapt_fail(WAPT_E_INVALID, "wapt_render renders all samples: sample_begin=0, sample_count=psamples");
+    HIPCHK(hipSetDevice(s->device));
+    size_t n = (size_t)s->ks.cam.resI * s->ks.cam.resJ * 3;
+    float* d_sum = nullptr;
+    HIPCHK(hipMalloc((void**)&d_sum, n * sizeof(float)));
+    hipError_t e = hipMemsetAsync(d_sum, 0, n * sizeof(float), s->stream);
+    int rc = e == hipSuccess ? wapt_render_accumulate(s, prm, d_sum, stats) : wapt_fail(WAPT_E_HIP, hipGetErrorString(e));
+    if (rc == WAPT_OK) {
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d_sum, d_sum, n,
+                           1.0f / (float)prm->psamples);
+        e = hipMemcpyAsync(fb, d_sum, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        if (e != hipSuccess) rc = wapt_fail(WAPT_E_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_sum);
+    return rc;
+}
+
+extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wapt_hit* d_hits,
+                                     wapt_trace_counters* counters, float* ms) {
+    if (!s || (n && (!d_rays || !d_hits))) return wapt_fail(WAPT_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemsetAsync(s->d_rays, 0, 4 * sizeof(unsigned long long), s->stream));
+    hipEvent_t a = nullptr, b = nullptr;
+    if (ms) {
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        HIPCHK(hipEventRecord(a, s->stream));
+    }
+    if (n) {
+        if (counters)
+            hipLaunchKernelGGL(k_intersect<true>, dim3(s->grid), dim3(WAPT_BLOCK), 0, s->stream, s->ks.tm,
+                               (const float4*)d_rays, n, (float*)d_hits, s->d_rays);
+        else
+            hipLaunchKernelGGL(k_intersect<false>, dim3(s->grid), dim3(WAPT_BLOCK), 0, s->stream, s->ks.tm,
+                               (const float4*)d_rays, n, (float*)d_hits, s->d_rays);
+    }
+    if (ms) HIPCHK(hipEventRecord(b, s->stream));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, s->d_rays, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    if (ms) {
+        (void)hipEventElapsedTime(ms, a, b);
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
+    if (counters) {
+        counters->rays = n;
+        counters->node_visits = h[0];
+        counters->tri_tests = h[1];
+        counters->stack_spills = h[2];
+    }
+    if (h[3]) return wapt_fail(WAPT_E_LIMIT, "traversal stack overflow");
+    return WAPT_OK;
+}
+
+extern "C" int wapt_intersect(wapt_scene* s, const wapt_ray* rays, uint32_t n, wapt_hit* hits) {
+    if (!s || (n && (!rays || !hits))) return wapt_fail(WAPT_E_INVALID, "null argument");
+    if (n == 0) return WAPT_OK;
+    HIPCHK(hipSetDevice(s->device));
+    wapt_ray* d_r = nullptr;
+    wapt_hit* d_h = nullptr;
+    HIPCHK(hipMalloc((void**)&d_r, (size_t)n * sizeof(wapt_ray)));
+    hipError_t e = hipMalloc((void**)&d_h, (size_t)n * sizeof(wapt_hit));
+    if (e != hipSuccess) {
+        (void)hipFree(d_r);
+        return wapt_fail(WAPT_E_HIP, hipGetErrorString(e));
+    }
+    int rc = WAPT_OK;
+    e = hipMemcpy(d_r, rays, (size_t)n * sizeof(wapt_ray), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = wapt_fail(WAPT_E_HIP, hipGetErrorString(e));
+    if (rc == WAPT_OK) rc = wapt_intersect_device(s, d_r, n, d_h, nullptr, nullptr);
+    if (rc == WAPT_OK) {
+        e = hipMemcpy(hits, d_h, (size_t)n * sizeof(wapt_hit), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = wapt_fail(WAPT_E_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_r);
+    (void)hipFree(d_h);
+    return rc;
+}
