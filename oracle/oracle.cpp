@@ -319,24 +319,35 @@ static void build_bvh(oracle_scene* s) {
 
 // ------------------------------------------------------------------ closest hit (stand-in for rtcIntersect1, src/content.cpp:97)
 
-static inline bool tri_hit(const Tri& T, const double* o, const double* d, double tnear, double tfar, double* t_out) {
-    double pv[3] = {d[1] * T.e2[2] - d[2] * T.e2[1], d[2] * T.e2[0] - d[0] * T.e2[2], d[0] * T.e2[1] - d[1] * T.e2[0]};
-    double det = T.e1[0] * pv[0] + T.e1[1] * pv[1] + T.e1[2] * pv[2];
-    if (det == 0.0) return false;
-    double inv = 1.0 / det;
-    double tv[3] = {o[0] - T.v0[0], o[1] - T.v0[1], o[2] - T.v0[2]};
-    double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * inv;
-    if (!(u >= 0.0)) return false;
-    double qv[3] = {tv[1] * T.e1[2] - tv[2] * T.e1[1], tv[2] * T.e1[0] - tv[0] * T.e1[2], tv[0] * T.e1[1] - tv[1] * T.e1[0]};
-    double v = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) * inv;
-    if (!(v >= 0.0) || !(u + v <= 1.0)) return false;
-    double t = (T.e2[0] * qv[0] + T.e2[1] * qv[1] + T.e2[2] * qv[2]) * inv;
-    if (!(t > tnear) || !(t <= tfar)) return false;
-    *t_out = t;
+// Ray/triangle test in the form Embree 3's default triangle intersector uses (embree3, version not pinned
+// by the reference; kernels/geometry/triangle_intersector_moeller.h: C = v0 - org, R = C x D,
+// U = R.e2, V = R.e1 and T = Ng.C signed by den = Ng.D, valid when U >= 0, V >= 0, U+V <= |den| and
+// |den|*tnear < T <= |den|*tfar with e1 = v0-v1, e2 = v2-v0, Ng = e2 x e1), evaluated in double.
+static inline bool tri_hit(const Tri& T_, const double* o, const double* d, double tnear, double tfar, double* t_out) {
+    // T_.e1 = v1-v0 and T_.e2 = v2-v0 are stored; Embree's e1 is the negated first edge
+    double e1[3] = {-T_.e1[0], -T_.e1[1], -T_.e1[2]};
+    const double* e2 = T_.e2;
+    double Ng[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};
+    double C[3] = {T_.v0[0] - o[0], T_.v0[1] - o[1], T_.v0[2] - o[2]};
+    double R[3] = {C[1] * d[2] - C[2] * d[1], C[2] * d[0] - C[0] * d[2], C[0] * d[1] - C[1] * d[0]};
+    double den = Ng[0] * d[0] + Ng[1] * d[1] + Ng[2] * d[2];
+    if (den == 0.0) return false;
+    double absDen = fabs(den), sgn = den < 0.0 ? -1.0 : 1.0;
+    double U = (R[0] * e2[0] + R[1] * e2[1] + R[2] * e2[2]) * sgn;
+    double V = (R[0] * e1[0] + R[1] * e1[1] + R[2] * e1[2]) * sgn;
+    if (!(U >= 0.0) || !(V >= 0.0) || !(U + V <= absDen)) return false;
+    double T = (Ng[0] * C[0] + Ng[1] * C[1] + Ng[2] * C[2]) * sgn;
+    if (!(absDen * tnear < T) || !(T <= absDen * tfar)) return false;
+    *t_out = T / absDen;
     return true;
 }
 
+// optional event log of one path (oracle_debug_path)
+static thread_local std::vector<float>* tl_log = nullptr;
+static inline void log_event(float kind, float depth, f3 p, col c);
 static thread_local uint64_t tl_rays = 0;
+static thread_local uint64_t tl_shadow_rays = 0;
+static std::atomic<uint64_t> g_shadow_rays{0};
 
 // Returns triangle index or -1; *t receives the hit distance.  Ties go to the lower triangle index.
 static int closest_hit(const oracle_scene* s, const float* org, const float* dir, float tnear, float tfar, double* t_hit,
@@ -397,6 +408,12 @@ static int closest_hit(const oracle_scene* s, const float* org, const float* dir
     }
     *t_hit = best;
     return hit;
+}
+
+static inline void log_event(float kind, float depth, f3 p, col c) {
+    if (!tl_log) return;
+    float r[8] = {kind, depth, p.x, p.y, p.z, c.r, c.g, c.b};
+    tl_log->insert(tl_log->end(), r, r + 8);
 }
 
 // wa_primitive as filled by wa_content::traceFAST (src/content.cpp:91-123)
@@ -588,6 +605,7 @@ struct Renderer {
         bool enteringSurface = false;
         Intr intr;
         for (int it = 0; it < 4096; it++) {
+            tl_shadow_rays++;
             bool hit = traceFAST(sc, P0, ABn, &intr);
             if (hit) d += mag(intr.P - P0);
             else d = (float)(2.0 * AB_l);
@@ -651,6 +669,7 @@ struct Renderer {
                 float NdotWi = dot(Wi, N);
                 if (NdotWi < 0.0) continue;
                 col vis = visibility(P, LP);
+                log_event(2.f, (float)l, LP, vis);
                 if (iszero(vis)) continue;
                 float scalar = (float)(rls * (float)(1.0 / M_PI_REF) * NdotWi * rpdf);
                 Lo += shader.kd * vis * Li * scalar;
@@ -809,6 +828,7 @@ struct Renderer {
             return volumeScattering(-1, sc->global, P0, P1, depth, true, 1.0f, key, stream);
         }
         const Shader& shader = sc->shaders[intr.objID];
+        log_event(1.f, (float)depth, intr.P, col{(float)intr.objID, intr.N.x + 10.f * intr.N.y + 100.f * intr.N.z, 0.f});
         f3 N1f;
         const Shader* medium1;
         int objID;
@@ -917,10 +937,12 @@ int oracle_render(const oracle_scene* s, const OParams* p, float* fb, int thread
     threads = std::max(1, threads);
     int W = s->cam.resI, H = s->cam.resJ;
     std::atomic<uint64_t> rays{0};
+    g_shadow_rays = 0;
     std::vector<std::thread> th;
     for (int t = 0; t < threads; t++)
         th.emplace_back([&, t]() {
             tl_rays = 0;
+            tl_shadow_rays = 0;
             Renderer R;
             R.sc = s;
             R.hs = p->hsamples;
@@ -945,11 +967,35 @@ int oracle_render(const oracle_scene* s, const OParams* p, float* fb, int thread
                     fb[(j * W + i) * 3 + 2] = pixelValue.b;
                 }
             rays += tl_rays;
+            g_shadow_rays += tl_shadow_rays;
         });
     for (auto& x : th) x.join();
     if (rays_out) *rays_out = rays.load();
     return 0;
 }
+
+// Event log of the path of one pixel sample: records of 8 floats (kind, depth|light, x, y, z, r, g, b);
+// kind 1 = surface hit (r = object), kind 2 = light sample after its shadow walk (rgb = visibility).
+int oracle_debug_path(const oracle_scene* s, const OParams* p, int i, int j, int sample, float* out, int max_records) {
+    std::vector<float> log;
+    tl_log = &log;
+    Renderer R;
+    R.sc = s; R.hs = p->hsamples; R.ls = p->lsamples; R.td = p->max_depth; R.me = p->me; R.mr = p->mr;
+    R.pixel = (uint32_t)(j * s->cam.resI + i);
+    uint32_t key = key_root(p->seed, (uint32_t)sample);
+    uint32_t stream = stream_of(key, R.pixel);
+    f3 P, D;
+    camera_ray(s->cam, i, j, rnd(stream, DIM_CAM0), rnd(stream, DIM_CAM1), &P, &D);
+    col v = R.radiance(P, -1.0 * D, 0, true, CAMERA_RAY, s->global, key);
+    tl_log = nullptr;
+    log_event(0, 0, P, v);
+    int n = (int)std::min<size_t>(log.size() / 8, (size_t)max_records);
+    memcpy(out, log.data(), (size_t)n * 8 * sizeof(float));
+    return n;
+}
+
+// closest-hit queries that the shadow walks of the last oracle_render issued
+uint64_t oracle_last_shadow_rays(void) { return g_shadow_rays.load(); }
 
 // ---- single functions, for known-answer tests
 

@@ -10,12 +10,20 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwapt.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("WAPT_LIB", "libwapt.so"))  # WAPT_LIB: alternative build, e.g. a debug one
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build the HIP library first (make -C pathtracer_amd/csrc); "
         "pathtracer_amd has no CPU path")
+
+# PyTorch wheels carry their own copy of the HIP runtime.  Two copies in one process cannot both own the
+# GPU ("No HIP GPUs are available" from whichever initialises second), so when torch is installed it is
+# imported first: its runtime has the same soname as the one libwapt.so asks for and is then shared.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
 
 lib = C.CDLL(LIB_PATH)
 

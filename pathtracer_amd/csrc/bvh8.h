@@ -16,8 +16,10 @@
 // triangles.  Slots are assigned at build time so that visiting inner hits in
 // descending (slot ^ octant_inverse) order is front to back.
 //
-// Triangle = 48 bytes = three 16-byte loads: v0, e1=v1-v0, e2=v2-v0 and the
-// (geomID, primID) pair of the reference's hit record (src/content.cpp:110-111).
+// Triangle = 48 bytes = three 16-byte loads: the three vertices exactly as
+// given (the watertight edge test needs bit-identical copies of shared
+// vertices) and the (geomID, primID) pair of the reference's hit record
+// (src/content.cpp:110-111).
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -37,8 +39,8 @@ static_assert(sizeof(Bvh8Node) == 80, "node must be 80 bytes");
 
 struct Bvh8Tri {
     float v0[3];
-    float e1[3];
-    float e2[3];
+    float v1[3];
+    float v2[3];
     int32_t obj;
     int32_t prim;
     uint32_t pad;

@@ -386,8 +386,8 @@ bool bvh8_build(const float* verts, const int32_t* obj, const int32_t* prim, uin
                     Bvh8Tri T;
                     for (int a = 0; a < 3; a++) {
                         T.v0[a] = v[a];
-                        T.e1[a] = v[3 + a] - v[a];
-                        T.e2[a] = v[6 + a] - v[a];
+                        T.v1[a] = v[3 + a];
+                        T.v2[a] = v[6 + a];
                     }
                     T.obj = obj ? obj[t] : 0;
                     T.prim = prim ? prim[t] : (int32_t)t;

@@ -53,6 +53,7 @@ struct KQueues {
     uint32_t* cnt;           // CNT_*
     unsigned long long* rays;  // closest-hit queries issued by shadow and probe kernels
     float* sum;              // W*H*3 radiance sums
+    uint32_t debug_pixel;    // only read by builds with -DWAPT_DEBUG_PIXEL (per-pixel printf trace)
 };
 
 struct KParams {

@@ -60,6 +60,26 @@ __device__ __forceinline__ uint32_t hit4(uint32_t nlx, uint32_t nly, uint32_t nl
     return mask;
 }
 
+// Point on a ray, rounded like the scalar expression org + t*dir without a fused
+// multiply-add (content.cpp:98-100 as a non-FMA build evaluates it).  Hit points seed the next
+// ray; at grazing angles one ulp decides whether that ray re-hits the surface it starts on
+// beyond tnear = 0.001, so the rounding is kept the same as in the CPU checker.
+__device__ __forceinline__ V3 point_at(V3 o, float t, V3 d) {
+#pragma clang fp contract(off)
+    float mx = t * d.x, my = t * d.y, mz = t * d.z;
+    return v3(o.x + mx, o.y + my, o.z + mz);
+}
+
+// Unnormalised geometric normal (v1-v0)x(v2-v0) and ids of triangle `ti`.
+__device__ __forceinline__ V3 tri_normal(const float4* __restrict__ tris, uint32_t ti, int* obj, int* prim) {
+    const float4* tp = tris + (size_t)ti * 3;
+    float4 a = tp[0], b = tp[1], c = tp[2];
+    V3 p0 = v3(a.x, a.y, a.z), p1 = v3(a.w, b.x, b.y), p2 = v3(b.z, b.w, c.x);
+    *obj = (int)__float_as_uint(c.y);
+    *prim = (int)__float_as_uint(c.z);
+    return cross(p1 - p0, p2 - p0);
+}
+
 // Traces one ray.  On return tmax is the hit distance (unchanged on a miss)
 // and the result is the index of the hit triangle in the BVH's triangle array
 // or 0xffffffff.  `lds` points at this lane's column of the block's short
@@ -133,17 +153,33 @@ __device__ __forceinline__ uint32_t trace_ray(const TraceMem& m, V3 o, V3 d, flo
             const float4* tp = m.tris + (size_t)ti * 3;
             float4 a = tp[0], b = tp[1], c = tp[2];
             if (COUNT) cnt.tris++;
-            V3 v0 = v3(a.x, a.y, a.z), e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, c.x);
-            V3 pv = cross(d, e2);
-            float det = dot(e1, pv);
-            float inv = 1.0f / det;
-            V3 tv = o - v0;
-            float u = dot(tv, pv) * inv;
-            V3 qv = cross(tv, e1);
-            float v = dot(d, qv) * inv;
-            float t = dot(e2, qv) * inv;
-            if (det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.0f && t > tmin && t <= tmax) {
-                tmax = t;
+            // Ray/triangle test in the form Embree 3 uses for its default (non-robust) triangle
+            // intersector (kernels/geometry/triangle_intersector_moeller.h, Moeller-Trumbore with
+            // C = v0 - org, R = C x D, unnormalised edge tests against |den|): the reference's
+            // closest hits come from that code (src/content.cpp:97), so its edge behaviour is the
+            // one to follow.  Two-sided, interval (tmin, tmax].
+            V3 p0 = v3(a.x, a.y, a.z), p1 = v3(a.w, b.x, b.y), p2 = v3(b.z, b.w, c.x);
+            V3 e1 = p0 - p1, e2 = p2 - p0;
+            V3 Ng = cross(e2, e1);
+            V3 Cv = p0 - o;
+            V3 R = cross(Cv, d);
+            float den = dot(Ng, d);
+            float absDen = fabsf(den);
+            float sgn = den < 0.f ? -1.0f : 1.0f;
+            float U = dot(R, e2) * sgn;
+            float V = dot(R, e1) * sgn;
+            float T = dot(Ng, Cv) * sgn;
+            if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * tmin < T && T <= absDen * tmax) {
+                // The accept tests run in fp32; the distance that is kept is the same quotient
+                // T/|den| evaluated in fp64 (a few dozen operations on accepted hits only), which
+                // removes the 1e-5-level error fp32 shows on thin, distant triangles.
+                double e1x = (double)p0.x - p1.x, e1y = (double)p0.y - p1.y, e1z = (double)p0.z - p1.z;
+                double e2x = (double)p2.x - p0.x, e2y = (double)p2.y - p0.y, e2z = (double)p2.z - p0.z;
+                double nx_ = e2y * e1z - e2z * e1y, ny_ = e2z * e1x - e2x * e1z, nz_ = e2x * e1y - e2y * e1x;
+                double num = nx_ * ((double)p0.x - o.x) + ny_ * ((double)p0.y - o.y) + nz_ * ((double)p0.z - o.z);
+                double dd = nx_ * d.x + ny_ * d.y + nz_ * d.z;
+                float tr = (float)(num / dd);
+                tmax = (tr > tmin) ? tr : T / absDen;
                 hit = ti;
             }
         }

@@ -142,12 +142,9 @@ __device__ __forceinline__ void load_hit(const KScene& sc, const KQueues& q, uin
     c.t = u2f(h.x);
     c.tri = h.y;
     if (c.tri == 0xffffffffu) return;
-    const float4* tp = sc.tm.tris + (size_t)c.tri * 3;
-    float4 a = tp[0], b = tp[1], cc = tp[2];
-    V3 e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, cc.x);
-    c.obj = (int)f2u(cc.y);
-    c.N = normalized(cross(e1, e2));
-    c.P = c.o + c.t * c.dir;  // content.cpp:98-100
+    int prim;
+    c.N = normalized(tri_normal(sc.tm.tris, c.tri, &c.obj, &prim));
+    c.P = point_at(c.o, c.t, c.dir);  // content.cpp:98-100
     c.entering = dot(c.N, -c.dir) > 0.0f;
 }
 
@@ -161,6 +158,12 @@ __device__ __forceinline__ V3 surface_weight(const KScene& sc, const HitCtx& c) 
     V3 w = c.beta * attenuation(m0, mag(c.P - c.o));
     return (1.0f / p_surface(info_depth(c.info))) * w;
 }
+
+#ifdef WAPT_DEBUG_PIXEL
+#define DBG(pix, ...) do { if ((pix) == q.debug_pixel) printf(__VA_ARGS__); } while (0)
+#else
+#define DBG(pix, ...) do { } while (0)
+#endif
 
 #define GRID_LOOP(var, n)                                                                       \
     for (uint32_t var = blockIdx.x * blockDim.x + threadIdx.x, _n = ((n) + 63u) & ~63u; var < _n; \
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_head(KScene sc, KQueues q, KPara
             HitCtx c = {};
             load_task(q, depth, start, i, c);
             load_hit(sc, q, i, c);
+            DBG(c.pixel, "head d=%d key=%08x o=(%.6f %.6f %.6f) dir=(%.7f %.7f %.7f) t=%.6f tri=%u P=(%.6f %.6f %.6f) obj=%d beta=%g\n", depth, c.key, c.o.x, c.o.y, c.o.z, c.dir.x, c.dir.y, c.dir.z, c.t, c.tri, c.P.x, c.P.y, c.P.z, c.obj, c.beta.x);
             if (c.tri == 0xffffffffu) {
                 // cpp:221-230: the segment to the world sphere is lit through the GLOBAL medium
                 const DMaterial& g = sc.mats[sc.n_objects];
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shade_lambert(KScene sc, KQueues
                         }
                     }
                 }
+                if (valid) DBG(c.pixel, "nee d=%d key=%08x emit=%d LP=(%.5f %.5f %.5f) wt=%g\n", depth, c.key, (int)emit, LP.x, LP.y, LP.z, wt.x);
                 push_shadow(q, emit, c.P, LP, wt, c.pixel);
             }
         }
@@ -530,14 +535,12 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
             V3 P1;
             bool entering = false, opaque = false;
             int obj = -1;
-            V3 hp = P0 + tmax * ABn;
+            V3 hp = point_at(P0, tmax, ABn);
             if (tri != 0xffffffffu) d += mag(hp - P0);
             else d = 2.0f * ABl;
             if (d <= ABl + WAPT_TRACE_BIAS) {
-                const float4* tp = sc.tm.tris + (size_t)tri * 3;
-                float4 ta = tp[0], tb = tp[1], tcx = tp[2];
-                V3 N = normalized(cross(v3(ta.w, tb.x, tb.y), v3(tb.z, tb.w, tcx.x)));
-                obj = (int)f2u(tcx.y);
+                int prim;
+                V3 N = normalized(tri_normal(sc.tm.tris, tri, &obj, &prim));
                 const DMaterial& m = sc.mats[obj];
                 P1 = hp;
                 entering = dot(ABn, N) < 0.0f;
@@ -563,6 +566,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
             P0 = P1;
             cur = entering ? obj : global_m;
         }
+        DBG(pixel, "shadow A=(%.5f %.5f %.5f) B=(%.5f %.5f %.5f) lit=%d V=%g w=%g d=%.6f ABl=%.6f\n", A.x, A.y, A.z, B.x, B.y, B.z, (int)lit, V.x, w4.x, d, ABl);
         if (lit) add_rgb(q.sum, pixel, v3(w4.x, w4.y, w4.z) * V);
     }
     rays = wave_sum(rays);
@@ -589,10 +593,9 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
         uint32_t tri = trace_ray<false>(sc.tm, S, dir, WAPT_TRACE_BIAS, tmax, &s_stack[threadIdx.x], glane, tc);
         rays++;
         if (tri == 0xffffffffu) continue;
-        const float4* tp = sc.tm.tris + (size_t)tri * 3;
-        float4 ta = tp[0], tb = tp[1], tcx = tp[2];
-        int obj = (int)f2u(tcx.y);
-        V3 hp = S + tmax * dir;
+        int obj, prim;
+        V3 Ng = tri_normal(sc.tm.tris, tri, &obj, &prim);
+        V3 hp = point_at(S, tmax, dir);
         const DLight& L = sc.lights[light];
         if (kind == 0) {
             if (obj != light) continue;
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
             add_rgb(q.sum, pixel, mis * (w * ld3(L.Li) * att));
         } else {
             if (obj != medium) continue;
-            V3 N = normalized(cross(v3(ta.w, tb.x, tb.y), v3(tb.z, tb.w, tcx.x)));
+            V3 N = normalized(Ng);
             float F;
             V3 D1 = refract_dir(N, -dir, M.ior, &F);
             if (is_zero(D1)) continue;
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
             if (tri1 == 0xffffffffu) continue;
             int obj1 = (int)f2u(sc.tm.tris[(size_t)tri1 * 3 + 2].y);
             if (obj1 != light) continue;
-            V3 hp1 = hp + tmax1 * dir1;
+            V3 hp1 = point_at(hp, tmax1, dir1);
             V3 att = attenuation(sc.mats[sc.n_objects], mag(hp1 - hp)) * attenuation(M, mag(hp - S));
             add_rgb(q.sum, pixel, (1.0f - F) * (w * ld3(L.Li) * att));
         }
@@ -643,12 +646,11 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const flo
             h[2] = u2f(0xffffffffu);
             h[3] = h[4] = h[5] = 0.f;
         } else {
-            const float4* tp = tm.tris + (size_t)tri * 3;
-            float4 ta = tp[0], tb = tp[1], tcx = tp[2];
-            V3 Ng = cross(v3(ta.w, tb.x, tb.y), v3(tb.z, tb.w, tcx.x));
+            int obj, prim;
+            V3 Ng = tri_normal(tm.tris, tri, &obj, &prim);
             h[0] = tmax;
-            h[1] = tcx.z;  // prim
-            h[2] = tcx.y;  // obj
+            h[1] = u2f((uint32_t)prim);
+            h[2] = u2f((uint32_t)obj);
             h[3] = Ng.x;
             h[4] = Ng.y;
             h[5] = Ng.z;
@@ -1060,6 +1062,7 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     kp.slots_per_sample = kp.tilesX * (uint32_t)((H + 7) / 8) * 64u;
     KQueues q = s->kq;
     q.sum = d_sum;
+    q.debug_pixel = env_u32("WAPT_DEBUG_PIXEL", 0xffffffffu);
     const KScene& ks = s->ks;
     hipStream_t st = s->stream;
     const dim3 grid(s->grid), block(WAPT_BLOCK);

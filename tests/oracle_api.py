@@ -29,6 +29,7 @@ def lib():
         l.oracle_scene_destroy.argtypes = [C.c_void_p]
         l.oracle_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
         l.oracle_render.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        l.oracle_last_shadow_rays.restype = C.c_uint64
         l.oracle_rand.restype = C.c_float
         l.oracle_rand.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         l.oracle_key_child.restype = C.c_uint32
@@ -79,6 +80,7 @@ class OracleScene:
         rc = lib().oracle_render(self._h, C.byref(p), fb.ctypes.data, threads, C.byref(rays))
         assert rc == 0
         self.rays = rays.value
+        self.shadow_rays = lib().oracle_last_shadow_rays()
         return fb
 
     def close(self):
