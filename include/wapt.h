@@ -112,7 +112,8 @@ typedef struct wapt_render_params {
     uint64_t seed;         /* counter-based RNG seed */
     int32_t sample_begin;  /* this call renders global sample indices      */
     int32_t sample_count;  /*   [sample_begin, sample_begin+sample_count)  */
-    int32_t profile;       /* 1: bracket every kernel launch with HIP events */
+    int32_t profile;       /* bit 0: bracket every kernel launch with HIP events;
+                              bit 1: run the counting build of the closest-hit kernel */
     int32_t reserved;
 } wapt_render_params;
 
@@ -125,6 +126,8 @@ typedef struct wapt_stats {
     double ms_raygen, ms_trace, ms_head, ms_shade, ms_volume, ms_shadow, ms_probe;
     uint64_t n_trace_launches, n_trace_rays;
     uint64_t n_shadow_launches, n_shadow_rays;
+    /* filled when profile bit 1 is set: totals over the closest-hit kernel's rays */
+    uint64_t trace_node_visits, trace_tri_tests;
 } wapt_stats;
 
 typedef struct wapt_ray {

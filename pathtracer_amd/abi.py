@@ -42,7 +42,8 @@ class Stats(C.Structure):
                 ("ms_raygen", C.c_double), ("ms_trace", C.c_double), ("ms_head", C.c_double), ("ms_shade", C.c_double),
                 ("ms_volume", C.c_double), ("ms_shadow", C.c_double), ("ms_probe", C.c_double),
                 ("n_trace_launches", C.c_uint64), ("n_trace_rays", C.c_uint64),
-                ("n_shadow_launches", C.c_uint64), ("n_shadow_rays", C.c_uint64)]
+                ("n_shadow_launches", C.c_uint64), ("n_shadow_rays", C.c_uint64),
+                ("trace_node_visits", C.c_uint64), ("trace_tri_tests", C.c_uint64)]
 
 
 class Ray(C.Structure):

@@ -63,4 +63,5 @@ struct KParams {
     int32_t sample_begin;
     uint32_t slots_per_sample;  // tilesX*tilesY*64
     uint32_t tilesX;
+    int32_t dense_raygen;       // W and H are multiples of 8: every slot is a pixel sample
 };

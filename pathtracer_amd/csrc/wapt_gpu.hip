@@ -18,17 +18,38 @@
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
-// Wave-level compaction: the lanes of a wave that have something to emit get
-// consecutive slots from ONE atomic on the queue counter.
-__device__ __forceinline__ uint32_t wave_push(uint32_t* counter, bool pred) {
+// Queue compaction.  Lanes that have something to emit get consecutive slots: a ballot
+// and a population count give each lane its rank inside the wave, the waves' totals are
+// scanned by the block's first wave, and the block takes ONE atomic on the queue counter.
+// (One returning atomic per wave on a single counter tops out near 90 per microsecond on this
+// chip, far below what the streaming kernels need; one per 1024-thread block is 16x fewer.)
+// Every thread of the block must call this together.
+#define WAPT_SBLOCK 1024
+__device__ __forceinline__ uint32_t block_push(uint32_t* counter, bool pred) {
+    __shared__ uint32_t s_cnt[WAPT_SBLOCK / 64];
+    __shared__ uint32_t s_off[WAPT_SBLOCK / 64];
     unsigned long long m = __ballot(pred);
-    if (m == 0ull) return 0u;
     uint32_t lane = lane_id();
-    uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, (int)leader);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    uint32_t wave = threadIdx.x >> 6;
+    uint32_t nw = blockDim.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t c = lane < nw ? s_cnt[lane] : 0u;
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < WAPT_SBLOCK / 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
+        }
+        uint32_t total = __shfl(x, (int)nw - 1);
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(counter, total);
+        base = __shfl(base, 0);
+        if (lane < nw) s_off[lane] = base + x - c;
+    }
+    __syncthreads();
+    return s_off[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -74,7 +95,7 @@ __device__ __forceinline__ bool finite_dir(V3 d) {
 __device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, bool pred, V3 o, V3 dir, V3 beta,
                                               uint32_t pixel, uint32_t info, uint32_t key) {
     pred = pred && finite_dir(dir);
-    uint32_t slot = wave_push(&q.cnt[CNT_R0 + depth_next], pred);
+    uint32_t slot = block_push(&q.cnt[CNT_R0 + depth_next], pred);
     if (!pred) return;
     if (slot >= q.capR) {
         atomicAdd(&q.cnt[CNT_OVERFLOW], 1u);
@@ -88,7 +109,7 @@ __device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, 
 
 __device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from, V3 to, V3 w, uint32_t pixel) {
     pred = pred && !(w.x == 0.f && w.y == 0.f && w.z == 0.f);
-    uint32_t slot = wave_push(&q.cnt[CNT_S], pred);
+    uint32_t slot = block_push(&q.cnt[CNT_S], pred);
     if (!pred) return;
     if (slot >= q.capS) {
         atomicAdd(&q.cnt[CNT_OVERFLOW], 1u);
@@ -102,7 +123,7 @@ __device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from
 __device__ __forceinline__ void push_probe(const KQueues& q, bool pred, V3 o, V3 dir, V3 w, uint32_t pixel,
                                            uint32_t info, int medium) {
     pred = pred && finite_dir(dir) && !(w.x == 0.f && w.y == 0.f && w.z == 0.f);
-    uint32_t slot = wave_push(&q.cnt[CNT_P], pred);
+    uint32_t slot = block_push(&q.cnt[CNT_P], pred);
     if (!pred) return;
     if (slot >= q.capP) {
         atomicAdd(&q.cnt[CNT_OVERFLOW], 1u);
@@ -166,19 +187,19 @@ __device__ __forceinline__ V3 surface_weight(const KScene& sc, const HitCtx& c) 
 #endif
 
 #define GRID_LOOP(var, n)                                                                       \
-    for (uint32_t var = blockIdx.x * blockDim.x + threadIdx.x, _n = ((n) + 63u) & ~63u; var < _n; \
+    for (uint32_t var = blockIdx.x * blockDim.x + threadIdx.x, _n = (((n) + blockDim.x - 1u) / blockDim.x) * blockDim.x; var < _n; \
          var += gridDim.x * blockDim.x)
 
 // =============================================================== kernels
 
-__global__ void k_reset(uint32_t* cnt, int r_slot) {
+__global__ void k_reset(uint32_t* cnt, int r_slot, uint32_t r_value) {
     uint32_t t = threadIdx.x;
     if (t <= CNT_P) cnt[t] = 0u;
-    if (r_slot >= 0 && t == 0) cnt[r_slot] = 0u;
+    if (r_slot >= 0 && t == 0) cnt[r_slot] = r_value;
 }
 
 // renderTile's sample loop + generateRayForPixel (cpp:122-132, fundamentals.cpp:306-327)
-__global__ __launch_bounds__(WAPT_BLOCK) void k_raygen(KScene sc, KQueues q, KParams p, unsigned long long p0, uint32_t n) {
+__global__ __launch_bounds__(WAPT_SBLOCK) void k_raygen(KScene sc, KQueues q, KParams p, unsigned long long p0, uint32_t n) {
     GRID_LOOP(i, n) {
         bool valid = i < n;
         unsigned long long path = p0 + i;
@@ -193,11 +214,22 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_raygen(KScene sc, KQueues q, KPa
         uint32_t stream = wapt_stream(key, pixel);
         V3 o, d;
         camera_ray(sc.cam, px, py, wapt_rand(stream, WAPT_DIM_CAM0), wapt_rand(stream, WAPT_DIM_CAM1), &o, &d);
-        push_radiance(q, 0, valid, o, d, v3(1.f, 1.f, 1.f), pixel, make_info(0, true, RAY_CAMERA, -1), key);
+        if (p.dense_raygen) {
+            // every slot of the batch is a pixel sample: the task goes to slot i, no compaction needed
+            if (i < n) {
+                q.RA[i] = make_float4(o.x, o.y, o.z, u2f(pixel));
+                q.RB[i] = make_float4(d.x, d.y, d.z, u2f(make_info(0, true, RAY_CAMERA, -1)));
+                q.RC[i] = make_float4(1.f, 1.f, 1.f, u2f(key));
+            }
+        } else {
+            push_radiance(q, 0, valid, o, d, v3(1.f, 1.f, 1.f), pixel, make_info(0, true, RAY_CAMERA, -1), key);
+        }
     }
 }
 
-// traceFAST for every task of the step (content.cpp:91-123)
+// traceFAST for every task of the step (content.cpp:91-123).  COUNT adds node-visit and
+// triangle-test tallies (rays[1], rays[2]) for the bytes-per-ray figure of the roofline.
+template <bool COUNT>
 __global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int depth, uint32_t start, uint32_t n) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,15 +238,22 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int 
         size_t k = (size_t)depth * q.capR + start + i;
         float4 a = q.RA[k], b = q.RB[k];
         float tmax = WAPT_TFAR;
-        uint32_t tri = trace_ray<false>(sc.tm, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, tmax,
+        uint32_t tri = trace_ray<COUNT>(sc.tm, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, tmax,
                                         &s_stack[threadIdx.x], glane, tc);
         q.hits[i] = make_uint2(f2u(tmax), tri);
+    }
+    if (COUNT) {
+        uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.tris);
+        if (lane_id() == 0) {
+            atomicAdd(&q.rays[1], (unsigned long long)a);
+            atomicAdd(&q.rays[2], (unsigned long long)b);
+        }
     }
     if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
 }
 
 // Head of radiance(): miss handling, roulette, emission, classification (cpp:218-263, 290)
-__global__ __launch_bounds__(WAPT_BLOCK) void k_head(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
+__global__ __launch_bounds__(WAPT_SBLOCK) void k_head(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
     GRID_LOOP(i, n) {
         bool valid = i < n;
         bool toL = false, toS = false, toD = false, toV = false;
@@ -244,19 +283,19 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_head(KScene sc, KQueues q, KPara
             }
         }
         uint32_t s;
-        s = wave_push(&q.cnt[CNT_QL], toL);
+        s = block_push(&q.cnt[CNT_QL], toL);
         if (toL) q.QL[s] = i;
-        s = wave_push(&q.cnt[CNT_QS], toS);
+        s = block_push(&q.cnt[CNT_QS], toS);
         if (toS) q.QS[s] = i;
-        s = wave_push(&q.cnt[CNT_QD], toD);
+        s = block_push(&q.cnt[CNT_QD], toD);
         if (toD) q.QD[s] = i;
-        s = wave_push(&q.cnt[CNT_QV], toV);
+        s = block_push(&q.cnt[CNT_QV], toV);
         if (toV) q.QV[s] = i;
     }
 }
 
 // Lambert surfaces: directReflection (cpp:345-381) + indirectReflection (cpp:383-405)
-__global__ __launch_bounds__(WAPT_BLOCK) void k_shade_lambert(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+__global__ __launch_bounds__(WAPT_SBLOCK) void k_shade_lambert(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
     uint32_t n = q.cnt[CNT_QL];
     GRID_LOOP(j, n) {
         bool valid = j < n;
@@ -317,7 +356,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shade_lambert(KScene sc, KQueues
 }
 
 // Mirror surfaces: the specular branch of reflection() (cpp:329-336)
-__global__ __launch_bounds__(WAPT_BLOCK) void k_shade_specular(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+__global__ __launch_bounds__(WAPT_SBLOCK) void k_shade_specular(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
     uint32_t n = q.cnt[CNT_QS];
     GRID_LOOP(j, n) {
         bool emit = false;
@@ -342,7 +381,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shade_specular(KScene sc, KQueue
 
 // Dielectric surfaces: the reflect-or-transmit choice of radiance() (cpp:266-280),
 // transmission() (cpp:296-311) and the dielectric branch of reflection() (cpp:329-341)
-__global__ __launch_bounds__(WAPT_BLOCK) void k_shade_dielectric(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+__global__ __launch_bounds__(WAPT_SBLOCK) void k_shade_dielectric(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
     uint32_t n = q.cnt[CNT_QD];
     GRID_LOOP(j, n) {
         bool emit = false;
@@ -386,7 +425,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shade_dielectric(KScene sc, KQue
 }
 
 // volumeScattering (cpp:429-621): ray march along the segment of one task
-__global__ __launch_bounds__(WAPT_BLOCK) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+__global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
     uint32_t n = q.cnt[CNT_QV];
     GRID_LOOP(j, n) {
         bool valid = j < n;
@@ -429,9 +468,14 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_volume(KScene sc, KQueues q, KPa
         V3 ss = ld3(M.ss), st = ld3(M.st);
         // the inside branch looks for the medium's own surface; the global medium has none
         bool inside_ok = inside && medium >= 0;
-        int rms_max = rms;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) rms_max = max(rms_max, __shfl_xor(rms_max, o));
+        // trip count of the march loop, uniform over the block (block_push needs every thread)
+        __shared__ int s_rms_max;
+        if (threadIdx.x == 0) s_rms_max = 0;
+        __syncthreads();
+        if (rms > 0) atomicMax(&s_rms_max, rms);
+        __syncthreads();
+        const int rms_max = s_rms_max;
+        __syncthreads();
         float rrms = rms > 0 ? 1.0f / (float)rms : 0.f;
         for (int s = 0; s < rms_max; s++) {
             bool act = valid && s < rms;
@@ -454,8 +498,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_volume(KScene sc, KQueues q, KPa
             float rls = 1.0f / (float)p.lsamples;
             for (int l = 0; l < sc.n_lights; l++) {
                 const DLight& L = sc.lights[l];
-                if (!__any(act && !inside)) {
-                } else {
+                if (__syncthreads_or(act && !inside)) {
                     // (i) in the open: light sampling and sphere sampling, MIS-weighted (cpp:487-553)
                     for (int k = 0; k < p.lsamples; k++) {
                         bool emit = false;
@@ -480,7 +523,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_volume(KScene sc, KQueues q, KPa
                         push_probe(q, act && !inside, S, dir, (4.0f * WAPT_PI) * cs, c.pixel, (uint32_t)l, medium);
                     }
                 }
-                if (__any(act && inside_ok)) {
+                if (__syncthreads_or(act && inside_ok)) {
                     // (ii) inside an object: 16 refracted connections per light (cpp:560-583)
                     V3 toL = normalized(ld3(L.centre) - S);
                     for (int k = 0; k < 16; k++) {
@@ -1060,12 +1103,14 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     kp.sample_begin = prm->sample_begin;
     kp.tilesX = (uint32_t)((W + 7) / 8);
     kp.slots_per_sample = kp.tilesX * (uint32_t)((H + 7) / 8) * 64u;
+    kp.dense_raygen = (W % 8 == 0 && H % 8 == 0) ? 1 : 0;
     KQueues q = s->kq;
     q.sum = d_sum;
     q.debug_pixel = env_u32("WAPT_DEBUG_PIXEL", 0xffffffffu);
     const KScene& ks = s->ks;
     hipStream_t st = s->stream;
     const dim3 grid(s->grid), block(WAPT_BLOCK);
+    const dim3 sgrid(std::max(1u, s->grid * WAPT_BLOCK / WAPT_SBLOCK)), sblock(WAPT_SBLOCK);
 
     // worst-case fan-out of one task of depth d (sizes the chunk taken from R[d])
     const int L = s->n_lights;
@@ -1088,13 +1133,13 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
         if (chunk_for(d) == 0)
             return wapt_fail(WAPT_E_LIMIT, "queue capacity too small for the fan-out of this scene and these settings");
 
-    Timer tm{s, prm->profile != 0, {}, 0};
+    Timer tm{s, (prm->profile & 1) != 0, {}, 0};
     std::vector<uint32_t> have((size_t)td + 2, 0u);
     const unsigned long long total = (unsigned long long)kp.slots_per_sample * (unsigned long long)prm->sample_count;
     unsigned long long issued = 0;
     uint64_t rays_trace = 0, n_trace_launches = 0, n_shadow_launches = 0;
     HIPCHK(hipMemsetAsync(s->d_rays, 0, 4 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, CNT_OVERFLOW);
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, CNT_OVERFLOW, 0u);
 
     for (;;) {
         int d = -1;
@@ -1106,29 +1151,36 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
         if (d < 0) {
             if (issued >= total) break;
             uint32_t n = (uint32_t)std::min<unsigned long long>(s->capR, total - issued);
-            hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, CNT_R0);
-            tm.run(FAM_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, grid, block, 0, st, ks, q, kp, issued, n); });
+            hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, CNT_R0, kp.dense_raygen ? n : 0u);
+            tm.run(FAM_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, sgrid, sblock, 0, st, ks, q, kp, issued, n); });
             issued += n;
-            HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            have[0] = std::min(s->h_cnt[CNT_R0], s->capR);
+            if (kp.dense_raygen) {
+                have[0] = n;
+            } else {
+                HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                have[0] = std::min(s->h_cnt[CNT_R0], s->capR);
+            }
             continue;
         }
         uint32_t n = std::min(have[d], chunk_for(d));
         uint32_t start = have[d] - n;
         have[d] = start;
-        hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, d < td ? CNT_R0 + d + 1 : -1);
-        tm.run(FAM_TRACE, [&] { hipLaunchKernelGGL(k_trace, grid, block, 0, st, ks, q, d, start, n); });
+        hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, d < td ? CNT_R0 + d + 1 : -1, 0u);
+        tm.run(FAM_TRACE, [&] {
+            if (prm->profile & 2) hipLaunchKernelGGL(k_trace<true>, grid, block, 0, st, ks, q, d, start, n);
+            else hipLaunchKernelGGL(k_trace<false>, grid, block, 0, st, ks, q, d, start, n);
+        });
         rays_trace += n;
         n_trace_launches++;
-        tm.run(FAM_HEAD, [&] { hipLaunchKernelGGL(k_head, grid, block, 0, st, ks, q, kp, d, start, n); });
+        tm.run(FAM_HEAD, [&] { hipLaunchKernelGGL(k_head, sgrid, sblock, 0, st, ks, q, kp, d, start, n); });
         tm.run(FAM_SHADE, [&] {
-            hipLaunchKernelGGL(k_shade_lambert, grid, block, 0, st, ks, q, kp, d, start);
-            hipLaunchKernelGGL(k_shade_specular, grid, block, 0, st, ks, q, kp, d, start);
-            hipLaunchKernelGGL(k_shade_dielectric, grid, block, 0, st, ks, q, kp, d, start);
+            hipLaunchKernelGGL(k_shade_lambert, sgrid, sblock, 0, st, ks, q, kp, d, start);
+            hipLaunchKernelGGL(k_shade_specular, sgrid, sblock, 0, st, ks, q, kp, d, start);
+            hipLaunchKernelGGL(k_shade_dielectric, sgrid, sblock, 0, st, ks, q, kp, d, start);
         });
         if (s->has_scatter) {
-            tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_volume, grid, block, 0, st, ks, q, kp, d, start); });
+            tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_volume, sgrid, sblock, 0, st, ks, q, kp, d, start); });
             tm.run(FAM_PROBE, [&] { hipLaunchKernelGGL(k_probe, grid, block, 0, st, ks, q); });
         }
         tm.run(FAM_SHADOW, [&] { hipLaunchKernelGGL(k_shadow, grid, block, 0, st, ks, q); });
@@ -1155,6 +1207,8 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
         stats->n_trace_rays = rays_trace;
         stats->n_shadow_launches = n_shadow_launches;
         stats->n_shadow_rays = h_rays[0];
+        stats->trace_node_visits = h_rays[1];
+        stats->trace_tri_tests = h_rays[2];
         if (tm.on) {
             double ms[FAM_N] = {0};
             for (auto& r : tm.recs) {

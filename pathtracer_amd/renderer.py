@@ -78,7 +78,7 @@ class udp_renderer:
             buffer = np.empty((H, W, 3), np.float32)
         if buffer.dtype != np.float32 or buffer.size != W * H * 3 or not buffer.flags.c_contiguous:
             raise ValueError("frame buffer must be contiguous float32 with W*H*3 elements")
-        self.params.profile = 1 if profile else 0
+        self.params.profile = int(profile)
         self.params.sample_begin, self.params.sample_count = 0, self.params.psamples
         capi.check(capi.wapt_render(self.content._h, C.byref(self.params), buffer.ctypes.data, C.byref(self.stats)))
         return buffer
@@ -86,7 +86,7 @@ class udp_renderer:
     def render_accumulate(self, d_sum_ptr, sample_begin, sample_count, profile=False):
         """Adds the radiance SUM of samples [sample_begin, sample_begin+sample_count) into a W*H*3 float buffer in
         device memory (spp sharding across GPUs: the caller reduces the buffers and divides by psamples)."""
-        self.params.profile = 1 if profile else 0
+        self.params.profile = int(profile)
         self.params.sample_begin, self.params.sample_count = sample_begin, sample_count
         capi.check(capi.wapt_render_accumulate(self.content._h, C.byref(self.params), d_sum_ptr, C.byref(self.stats)))
         return self.stats
