@@ -1,0 +1,172 @@
+"""Host side kept from the reference: .waff / OBJ / .fast readers, tone map and BMP writer of libwapt.so, checked
+against independent Python restatements of the file formats (reference src/myRenderer.cpp:90-119, 174-185, 315-726;
+src/raytracer.cpp:80-165)."""
+import ctypes as C
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import abi, meshes, scenes
+from pathtracer_amd.scene import Scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "pathtracer_amd", "myRenderer")
+
+WAFF = """v 0
+from  275 275 -755
+at    275 275 0
+up 0 1 0
+angle 40
+hither 0.1
+resolution 64 48
+width 1
+
+td 4
+me 0.5
+mr 0.02
+# medium section: comments are recognised from here on
+m 1 0.001 0.002 0.003 0.0001 0.0002 0.0003
+la 200 550 200  150 0 0  0 0 150  4000000 4000000 4000000
+ls 40 275 450 275 100 200 300
+l 10 20 30
+g diffuse  0.7 0.7 0.7  cornellBox.obj
+g specular  0.9 0.8 0.7  cornellBoxLeftWall.obj
+g dielectric 1 1.5 cornellBoxRightWall.obj
+# the next line does not set an ior: it inherits 1.5
+g sss 1  0.9 0.9 0.9  0.01 0.02 0.03  0 0 0  0.1 0.2 0.3  ball.fast
+g dielectricsss 1 1.3  1 1 1  0.001 0.002 0.003  0 0 0  0.03 0.03 0.03 ball.fast
+g diffuse 0.1 0.2 0.3 ball.fast
+"""
+
+
+@pytest.fixture()
+def scene_dir(tmp_path):
+    for f in ("cornellBox.obj", "cornellBoxLeftWall.obj", "cornellBoxRightWall.obj"):
+        shutil.copy(os.path.join(scenes.ASSET_DIR, f), tmp_path / f)
+    v, f = meshes.uv_sphere((100, 100, 100), 50, 8, 12)
+    meshes.write_fast(tmp_path / "ball.fast", v, f)
+    (tmp_path / "test.waff").write_text(WAFF)
+    return tmp_path
+
+
+def flags(m):
+    return m.flags
+
+
+def test_waff_loader(scene_dir):
+    sc = Scene.from_waff(str(scene_dir / "test.waff"))
+    cam = sc.camera
+    assert (cam.type, cam.resI, cam.resJ) == (0, 64, 48)
+    np.testing.assert_allclose(list(cam.P), [275, 275, -755])
+    np.testing.assert_allclose(list(cam.D), [0, 0, 1])
+    assert cam.fov_deg == 40 and cam.sensor_width == 1
+    assert (sc.td, sc.me, sc.mr) == (4, 0.5, pytest.approx(0.02))
+    g = sc.global_medium
+    assert not (g.flags & abi.MAT_CLEAR)
+    np.testing.assert_allclose(list(g.ss), [0.001, 0.002, 0.003], rtol=1e-6)
+    np.testing.assert_allclose(list(g.st), [0.0011, 0.0022, 0.0033], rtol=1e-6)
+    # three lights: area, sphere, point (= sphere of radius 1, default power 10000)
+    assert [l.type for l in sc.lights] == [0, 1, 1]
+    assert sc.lights[1].radius == 40 and list(sc.lights[1].P) == [275, 450, 275]
+    assert sc.lights[2].radius == 1 and list(sc.lights[2].power) == [10000, 10000, 10000]
+    # objects: 3 light placeholders (0.5 Lambert + light flag) then 6 meshes
+    assert len(sc.materials) == 9
+    for m in sc.materials[:3]:
+        assert m.flags == abi.MAT_OPAQUE | abi.MAT_CLEAR | abi.MAT_DIFFUSE | abi.MAT_LIGHT and list(m.kd) == [0.5] * 3
+    d, s, gl, sss, milk, d2 = sc.materials[3:]
+    assert d.flags == abi.MAT_OPAQUE | abi.MAT_CLEAR | abi.MAT_DIFFUSE and list(d.ks) == [0, 0, 0]
+    assert s.flags == abi.MAT_OPAQUE | abi.MAT_CLEAR | abi.MAT_SPECULAR
+    np.testing.assert_allclose(list(s.ks), [0.9, 0.8, 0.7], rtol=1e-6)
+    assert gl.flags == abi.MAT_CLEAR | abi.MAT_DIELECTRIC and gl.ior == 1.5 and list(gl.kt) == [1, 1, 1]
+    assert sss.flags == 0 and sss.ior == 1.5  # sticky ior; the parser never raises the sss flag
+    np.testing.assert_allclose(list(sss.st), [0.11, 0.22, 0.33], rtol=1e-6)
+    assert list(sss.ks) == [1, 1, 1]  # initialize() does not reset ks: inherited from the dielectric line
+    assert milk.flags == abi.MAT_DIELECTRICSSS and milk.ior == pytest.approx(1.3)
+    np.testing.assert_allclose(list(milk.ss), [0.03] * 3, rtol=1e-6)
+    assert d2.ior == pytest.approx(1.3)  # sticky again
+    np.testing.assert_allclose(list(d2.ss), [0.03] * 3, rtol=1e-6)  # and so are the medium coefficients
+    # geometry: only the area light owns triangles (two, prim 0); sphere lights keep their object slots
+    n_ball = len(meshes.read_fast(scene_dir / "ball.fast")[1])
+    counts = np.bincount(sc.tri_obj, minlength=9)
+    assert list(counts) == [2, 0, 0, 12, 2, 2, n_ball, n_ball, n_ball]
+    assert list(sc.tri_prim[:2]) == [0, 0]
+    np.testing.assert_allclose(sc.tri_verts[0], [[200, 550, 200], [350, 550, 200], [200, 550, 350]])
+    np.testing.assert_allclose(sc.tri_verts[1], [[350, 550, 350], [200, 550, 350], [350, 550, 200]])
+    # meshes agree with the independent Python OBJ reader
+    v, f = meshes.read_obj(scene_dir / "cornellBox.obj")
+    np.testing.assert_array_equal(sc.tri_verts[2:14], v[f])
+    assert sc.world_radius == 1100 and sc.world_center == (275.0, 275.0, 275.0)
+
+
+def test_waff_errors(scene_dir):
+    from pathtracer_amd import capi
+    bad = scene_dir / "bad.waff"
+    bad.write_text("v 0\nfrom 0 0 0\nat 0 0 1\n")
+    with pytest.raises(capi.WaptError, match="camera"):
+        Scene.from_waff(str(bad))
+    bad.write_text(WAFF.replace("g diffuse 0.1 0.2 0.3 ball.fast", "g plastic 1 2 3 ball.fast"))
+    with pytest.raises(capi.WaptError, match="unknown geometry type"):
+        Scene.from_waff(str(bad))
+    bad.write_text(WAFF.replace("ball.fast", "missing.fast"))
+    with pytest.raises(capi.WaptError, match="cannot open"):
+        Scene.from_waff(str(bad))
+
+
+def test_obj_reader_quads_negative_indices_and_first_shape_only(tmp_path):
+    from pathtracer_amd import capi
+    (tmp_path / "q.obj").write_text("# quad + later shape\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\n"
+                                    "f 1/1 2/1 3/1 4/1\nf -4 -3 -2\ng second\nv 5 5 5\nf 1 2 5\n")
+    capi.check(capi.wapt_convert_obj_to_fast(str(tmp_path / "q.obj").encode(), str(tmp_path / "q.fast").encode()))
+    v, f = meshes.read_fast(tmp_path / "q.fast")
+    assert len(v) == 5  # all positions are kept, as tinyobj's attrib.vertices
+    assert f.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2]]
+    v2, f2 = meshes.read_obj(tmp_path / "q.obj")
+    np.testing.assert_array_equal(f, f2)
+    # .fast layout: int32 nV, int32 nT, nV x 16 bytes, nT x 12 bytes
+    raw = open(tmp_path / "q.fast", "rb").read()
+    assert struct.unpack_from("<ii", raw) == (5, 3) and len(raw) == 8 + 5 * 16 + 3 * 12
+
+
+def test_tonemap_and_bmp_are_bit_exact(tmp_path):
+    from pathtracer_amd import renderer
+    rng = np.random.default_rng(3)
+    fb = rng.uniform(0, 1.5, size=(5, 7, 3)).astype(np.float32)
+    fb[0, 0] = [0.0, 1.0, 4.0]
+    want = np.clip(np.power(fb.astype(np.float64), 0.45).astype(np.float32), 0, 1)
+    got = renderer.tonemap(fb.copy())
+    np.testing.assert_array_equal(got, want)
+    path = tmp_path / "o.bmp"
+    renderer.write_bmp(str(path), got)
+    d = open(path, "rb").read()
+    W, H = 7, 5
+    assert len(d) == 138 + W * H * 4 and d[:2] == b"BM"
+    assert struct.unpack_from("<I", d, 2)[0] == len(d) and struct.unpack_from("<I", d, 10)[0] == 138
+    assert struct.unpack_from("<Iii", d, 14) == (124, W, H)
+    assert struct.unpack_from("<HHI", d, 26) == (1, 32, 3)
+    assert struct.unpack_from("<IIIII", d, 54) == (0x00FF0000, 0x0000FF00, 0x000000FF, 0xFF000000, 0x73524742)
+    px = np.frombuffer(d, np.uint8, W * H * 4, 138).reshape(H, W, 4)
+    expect = (got.astype(np.float64) * 255.0).astype(np.int32)  # truncation, myRenderer.cpp:713
+    np.testing.assert_array_equal(px[..., 2], expect[..., 0])
+    np.testing.assert_array_equal(px[..., 1], expect[..., 1])
+    np.testing.assert_array_equal(px[..., 0], expect[..., 2])
+    assert (px[..., 3] == 255).all()
+    # header bytes the reference leaves at zero stay zero
+    assert d[34:54] == bytes(20) and d[74:138] == bytes(64)
+
+
+def test_cli_help_and_convert(tmp_path):
+    if not os.path.exists(CLI):
+        pytest.skip("myRenderer not built")
+    out = subprocess.run([CLI, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--psamples" in out.stdout and "--convertOBJ" in out.stdout
+    shutil.copy(os.path.join(scenes.ASSET_DIR, "cornellBox.obj"), tmp_path / "box.obj")
+    out = subprocess.run([CLI, "--convertOBJ", "--obj", str(tmp_path / "box.obj")], capture_output=True, text=True)
+    assert out.returncode == 0 and "Convert OBJ mode" in out.stdout
+    v, f = meshes.read_fast(tmp_path / "box.fast")
+    assert len(v) == 48 and len(f) == 12
+    out = subprocess.run([CLI, "--bogus"], capture_output=True, text=True)
+    assert out.returncode != 0

@@ -1,0 +1,74 @@
+"""Pins the CPU checker (oracle/) to what the reference itself produced.
+
+Two sources, both data the reference's authors or the reference's own code produced:
+  * tests/golden/cornell_empty_known_answers.json — linear-radiance pixel values of the reference's estimator
+    for the bundled box scene (provenance in the file's note);
+  * tests/golden/published_image_patches.json — 9x9 patch means of the published, tone-mapped renders
+    (images/*.bmp), restricted to the part of the picture above the objects.
+The closest-hit boundary (Embree) has no fixture anywhere in the reference: parity there is unpinned.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api
+from pathtracer_amd import scenes
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def empty_box_1024():
+    sc = scenes.cornell(res=(60, 60), spheres=False)
+    o = oracle_api.OracleScene(sc)
+    fb = o.render(1024, seed=101, threads=8)
+    return fb, o.rays / (60 * 60 * 1024)
+
+
+def test_known_answers_of_the_reference_estimator(empty_box_1024):
+    fb, rays_per_path = empty_box_1024
+    k = json.load(open(os.path.join(GOLD, "cornell_empty_known_answers.json")))
+    # image mean: noise of a 3600-pixel mean is negligible, 1 % covers the reference's own run-to-run spread
+    np.testing.assert_allclose(fb.reshape(-1, 3).mean(0), k["image_mean"], rtol=0.01)
+    assert abs(rays_per_path - k["rays_per_path"]) < 0.1
+    for p in k["pixels"]:
+        got = fb[p["j"], p["i"]]
+        want = np.array(p["rgb"])
+        # single pixels: the reference's 4096-spp runs differ by 2.1 % (1 sigma, image-wide); a 1024-spp render
+        # has twice that; dim pixels (ceiling) are noisier still -> 12 % relative + 0.01 absolute
+        assert np.all(np.abs(got - want) <= 0.12 * want + 0.01), (p["what"], got, want)
+    # the directly visible light is noise free: 0.5*power/area/pi + reflected light
+    light = [p for p in k["pixels"] if p["what"].startswith("light")][0]
+    np.testing.assert_allclose(fb[light["j"], light["i"]], light["rgb"], rtol=2e-3)
+
+
+def test_published_images_above_the_objects():
+    """Tone-mapped oracle render of the empty box against the published dragonChrome/cornellBox renders in rows 0..250
+    (the objects below change the indirect light there by a few per cent; the two published images themselves differ
+    by 3.3 % in that region)."""
+    g = json.load(open(os.path.join(GOLD, "published_image_patches.json")))
+    n = 150
+    sc = scenes.cornell(res=(n, n), spheres=False)
+    fb = oracle_api.OracleScene(sc).render(128, seed=5, threads=8)
+    tm = np.clip(np.power(np.maximum(fb, 0), 0.45), 0, 1) * 255.0  # myRenderer.cpp:174-185, 713
+    scale = n / 600.0
+    for name in ("dragonChrome.bmp", "cornellBox.bmp"):
+        lit, dim = [], []
+        for p in g["images"][name]["patches"]:
+            i = int(p["col"] * scale)
+            j = n - 1 - int(p["row"] * scale)  # image row 0 is the top, frame buffer row 0 the bottom
+            want = np.array(p["rgb"])
+            if want.max() > 250:  # saturated (the light)
+                continue
+            got = tm[j - 1:j + 2, i - 1:i + 2].reshape(-1, 3).mean(0)
+            err = np.abs(got - want) / (want + 8.0)
+            # walls lit directly by the lamp do not care about the objects below; the ceiling is lit only by
+            # light bounced off the floor, part of which the published scenes' objects intercept
+            (lit if want.max() >= 150 else dim).append(err)
+        lit, dim = np.array(lit), np.array(dim)
+        assert len(lit) >= 12 and len(dim) >= 6
+        assert lit.max() < 0.06, (name, lit.max())
+        assert dim.max() < 0.25, (name, dim.max())
+        # the empty box can only be brighter than the published scenes, never darker
