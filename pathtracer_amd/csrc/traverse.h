@@ -80,116 +80,180 @@ __device__ __forceinline__ V3 tri_normal(const float4* __restrict__ tris, uint32
     return cross(p1 - p0, p2 - p0);
 }
 
-// Traces one ray.  On return tmax is the hit distance (unchanged on a miss)
-// and the result is the index of the hit triangle in the BVH's triangle array
-// or 0xffffffff.  `lds` points at this lane's column of the block's short
-// stack (element stride WAPT_BLOCK), `glane` is the lane's index in the launch.
+// State of one ray in flight.  A kernel keeps one per lane, calls trav_begin when the lane takes a
+// new ray, trav_step until it reports completion, and trav_finish for the final distance.  Keeping
+// the loop in the kernel lets a lane whose ray has ended pick up the next ray at once instead of
+// idling until the slowest ray of its wave is done (the waves' rays differ a lot in length once
+// paths have bounced).
+struct Trav {
+    V3 o, d;
+    float idx, idy, idz;
+    float tmin, tmax;
+    uint32_t octinv;
+    uint32_t hit;   // triangle index or 0xffffffff
+    uint2 G;        // current node group
+    int sp;
+};
+
+__device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, float tmax) {
+    const float tiny = 1e-18f;
+    t.o = o;
+    t.d = d;
+    t.idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+    t.idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+    t.idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+    t.tmin = tmin;
+    t.tmax = tmax;
+    t.octinv = (d.x < 0.f ? 0u : 4u) | (d.y < 0.f ? 0u : 2u) | (d.z < 0.f ? 0u : 1u);
+    t.hit = 0xffffffffu;
+    t.G = make_uint2(0u, 0x80000000u);  // root: "child 0 of group 0 is pending"
+    t.sp = 0;
+}
+
+// One traversal step: visit the nearest pending inner child (if any), test the triangles of the
+// leaves that node exposes, pop when the current group is exhausted.  Returns true when the ray is
+// finished.  `lds` points at this lane's column of the block's short stack (element stride
+// WAPT_BLOCK), `glane` is the lane's index in the launch.
+template <bool COUNT>
+__device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, uint2* lds, uint32_t glane, TraceCount& cnt) {
+    const bool nx = t.d.x < 0.f, ny = t.d.y < 0.f, nz = t.d.z < 0.f;
+    uint2 T;
+    if (t.G.y & 0xff000000u) {
+        uint32_t hits_imask = t.G.y;
+        uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
+        t.G.y &= ~(1u << bit);
+        if (t.G.y & 0xff000000u) {
+            if (t.sp < WAPT_LDS_STACK) {
+                lds[t.sp * WAPT_BLOCK] = t.G;
+                t.sp++;
+            } else if (t.sp < WAPT_STACK_CAP) {
+                m.spill[(size_t)(t.sp - WAPT_LDS_STACK) * m.spill_stride + glane] = t.G;
+                t.sp++;
+                if (COUNT) cnt.spills++;
+            } else {
+                cnt.overflow++;
+            }
+        }
+        uint32_t slot = (bit - 24u) ^ t.octinv;
+        uint32_t rel = __popc(hits_imask & 0xffu & ((1u << slot) - 1u));
+        uint32_t ni = t.G.x + rel;
+        const uint4* np = m.nodes + (size_t)ni * 5;
+        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        if (COUNT) cnt.nodes++;
+
+        float ax = __uint_as_float((n0.w & 0xffu) << 23) * t.idx;
+        float ay = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * t.idy;
+        float az = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * t.idz;
+        float ox = (__uint_as_float(n0.x) - t.o.x) * t.idx;
+        float oy = (__uint_as_float(n0.y) - t.o.y) * t.idy;
+        float oz = (__uint_as_float(n0.z) - t.o.z) * t.idz;
+        // near/far plane words per axis, by ray direction sign
+        uint32_t lx0 = nx ? n3.z : n2.x, lx1 = nx ? n3.w : n2.y;
+        uint32_t hx0 = nx ? n2.x : n3.z, hx1 = nx ? n2.y : n3.w;
+        uint32_t ly0 = ny ? n4.x : n2.z, ly1 = ny ? n4.y : n2.w;
+        uint32_t hy0 = ny ? n2.z : n4.x, hy1 = ny ? n2.w : n4.y;
+        uint32_t lz0 = nz ? n4.z : n3.x, lz1 = nz ? n4.w : n3.y;
+        uint32_t hz0 = nz ? n3.x : n4.z, hz1 = nz ? n3.y : n4.w;
+        const uint32_t octinv4 = t.octinv * 0x01010101u;
+        uint32_t hm = hit4(lx0, ly0, lz0, hx0, hy0, hz0, n1.z, ax, ay, az, ox, oy, oz, t.tmin, t.tmax, octinv4);
+        hm |= hit4(lx1, ly1, lz1, hx1, hy1, hz1, n1.w, ax, ay, az, ox, oy, oz, t.tmin, t.tmax, octinv4);
+        t.G = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
+        T = make_uint2(n1.y, hm & 0x00ffffffu);
+    } else {
+        T = t.G;
+        t.G = make_uint2(0u, 0u);
+    }
+
+    while (T.y) {
+        uint32_t k = (uint32_t)__ffs((int)T.y) - 1u;
+        T.y &= T.y - 1u;
+        uint32_t ti = T.x + k;
+        const float4* tp = m.tris + (size_t)ti * 3;
+        float4 a = tp[0], b = tp[1], c = tp[2];
+        if (COUNT) cnt.tris++;
+        // Ray/triangle test in the form Embree 3 uses for its default (non-robust) triangle
+        // intersector (kernels/geometry/triangle_intersector_moeller.h, Moeller-Trumbore with
+        // C = v0 - org, R = C x D, unnormalised edge tests against |den|): the reference's
+        // closest hits come from that code (src/content.cpp:97), so its edge behaviour is the
+        // one to follow.  Two-sided, interval (tmin, tmax].
+        V3 p0 = v3(a.x, a.y, a.z), p1 = v3(a.w, b.x, b.y), p2 = v3(b.z, b.w, c.x);
+        V3 e1 = p0 - p1, e2 = p2 - p0;
+        V3 Ng = cross(e2, e1);
+        V3 Cv = p0 - t.o;
+        V3 R = cross(Cv, t.d);
+        float den = dot(Ng, t.d);
+        float absDen = fabsf(den);
+        float sgn = den < 0.f ? -1.0f : 1.0f;
+        float U = dot(R, e2) * sgn;
+        float V = dot(R, e1) * sgn;
+        float Tn = dot(Ng, Cv) * sgn;
+        if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * t.tmin < Tn && Tn <= absDen * t.tmax) {
+            t.tmax = __fdividef(Tn, absDen);  // fp32 while searching, like Embree; see trav_finish
+            t.hit = ti;
+        }
+    }
+
+    if ((t.G.y & 0xff000000u) == 0u) {
+        if (t.sp == 0) return true;
+        t.sp--;
+        t.G = (t.sp < WAPT_LDS_STACK) ? lds[t.sp * WAPT_BLOCK]
+                                      : m.spill[(size_t)(t.sp - WAPT_LDS_STACK) * m.spill_stride + glane];
+    }
+    return false;
+}
+
+// Distance of the final hit: the same quotient T/|den| as in the search, re-evaluated in fp64 from
+// the float vertices (fp32 shows 1e-5-level relative error on thin, distant triangles; the
+// acceptance bar for hit distances is 1e-5).  Returns the distance (t.tmax on a miss).
+__device__ __forceinline__ float trav_finish(const TraceMem& m, const Trav& t) {
+    if (t.hit == 0xffffffffu) return t.tmax;
+    const float4* tp = m.tris + (size_t)t.hit * 3;
+    float4 a = tp[0], b = tp[1], c = tp[2];
+    double e1x = (double)a.x - a.w, e1y = (double)a.y - b.x, e1z = (double)a.z - b.y;
+    double e2x = (double)b.z - a.x, e2y = (double)b.w - a.y, e2z = (double)c.x - a.z;
+    double nx_ = e2y * e1z - e2z * e1y, ny_ = e2z * e1x - e2x * e1z, nz_ = e2x * e1y - e2y * e1x;
+    double num = nx_ * ((double)a.x - t.o.x) + ny_ * ((double)a.y - t.o.y) + nz_ * ((double)a.z - t.o.z);
+    double dd = nx_ * t.d.x + ny_ * t.d.y + nz_ * t.d.z;
+    float tr = (float)(num / dd);
+    return (tr > t.tmin) ? tr : t.tmax;
+}
+
+// Traces one ray to completion (kernels whose lanes do not stream rays).  On return tmax is the hit
+// distance (unchanged on a miss) and the result is the index of the hit triangle or 0xffffffff.
 template <bool COUNT>
 __device__ __forceinline__ uint32_t trace_ray(const TraceMem& m, V3 o, V3 d, float tmin, float& tmax, uint2* lds,
                                               uint32_t glane, TraceCount& cnt) {
-    const float tiny = 1e-18f;
-    float idx_ = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
-    float idy_ = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
-    float idz_ = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
-    const bool nx = d.x < 0.f, ny = d.y < 0.f, nz = d.z < 0.f;
-    const uint32_t octinv = (nx ? 0u : 4u) | (ny ? 0u : 2u) | (nz ? 0u : 1u);
-    const uint32_t octinv4 = octinv * 0x01010101u;
-
-    uint32_t hit = 0xffffffffu;
-    uint2 G = make_uint2(0u, 0x80000000u);  // root: "child 0 of group 0 is pending"
-    int sp = 0;
-
-    for (;;) {
-        uint2 T;
-        if (G.y & 0xff000000u) {
-            uint32_t hits_imask = G.y;
-            uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
-            G.y &= ~(1u << bit);
-            if (G.y & 0xff000000u) {
-                if (sp < WAPT_LDS_STACK) {
-                    lds[sp * WAPT_BLOCK] = G;
-                    sp++;
-                } else if (sp < WAPT_STACK_CAP) {
-                    m.spill[(size_t)(sp - WAPT_LDS_STACK) * m.spill_stride + glane] = G;
-                    sp++;
-                    if (COUNT) cnt.spills++;
-                } else {
-                    cnt.overflow++;
-                }
-            }
-            uint32_t slot = (bit - 24u) ^ octinv;
-            uint32_t rel = __popc(hits_imask & 0xffu & ((1u << slot) - 1u));
-            uint32_t ni = G.x + rel;
-            const uint4* np = m.nodes + (size_t)ni * 5;
-            uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-            if (COUNT) cnt.nodes++;
-
-            float ax = __uint_as_float((n0.w & 0xffu) << 23) * idx_;
-            float ay = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * idy_;
-            float az = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * idz_;
-            float ox = (__uint_as_float(n0.x) - o.x) * idx_;
-            float oy = (__uint_as_float(n0.y) - o.y) * idy_;
-            float oz = (__uint_as_float(n0.z) - o.z) * idz_;
-            // near/far plane words per axis, by ray direction sign
-            uint32_t lx0 = nx ? n3.z : n2.x, lx1 = nx ? n3.w : n2.y;
-            uint32_t hx0 = nx ? n2.x : n3.z, hx1 = nx ? n2.y : n3.w;
-            uint32_t ly0 = ny ? n4.x : n2.z, ly1 = ny ? n4.y : n2.w;
-            uint32_t hy0 = ny ? n2.z : n4.x, hy1 = ny ? n2.w : n4.y;
-            uint32_t lz0 = nz ? n4.z : n3.x, lz1 = nz ? n4.w : n3.y;
-            uint32_t hz0 = nz ? n3.x : n4.z, hz1 = nz ? n3.y : n4.w;
-            uint32_t hm = hit4(lx0, ly0, lz0, hx0, hy0, hz0, n1.z, ax, ay, az, ox, oy, oz, tmin, tmax, octinv4);
-            hm |= hit4(lx1, ly1, lz1, hx1, hy1, hz1, n1.w, ax, ay, az, ox, oy, oz, tmin, tmax, octinv4);
-            G = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
-            T = make_uint2(n1.y, hm & 0x00ffffffu);
-        } else {
-            T = G;
-            G = make_uint2(0u, 0u);
-        }
-
-        while (T.y) {
-            uint32_t k = (uint32_t)__ffs((int)T.y) - 1u;
-            T.y &= T.y - 1u;
-            uint32_t ti = T.x + k;
-            const float4* tp = m.tris + (size_t)ti * 3;
-            float4 a = tp[0], b = tp[1], c = tp[2];
-            if (COUNT) cnt.tris++;
-            // Ray/triangle test in the form Embree 3 uses for its default (non-robust) triangle
-            // intersector (kernels/geometry/triangle_intersector_moeller.h, Moeller-Trumbore with
-            // C = v0 - org, R = C x D, unnormalised edge tests against |den|): the reference's
-            // closest hits come from that code (src/content.cpp:97), so its edge behaviour is the
-            // one to follow.  Two-sided, interval (tmin, tmax].
-            V3 p0 = v3(a.x, a.y, a.z), p1 = v3(a.w, b.x, b.y), p2 = v3(b.z, b.w, c.x);
-            V3 e1 = p0 - p1, e2 = p2 - p0;
-            V3 Ng = cross(e2, e1);
-            V3 Cv = p0 - o;
-            V3 R = cross(Cv, d);
-            float den = dot(Ng, d);
-            float absDen = fabsf(den);
-            float sgn = den < 0.f ? -1.0f : 1.0f;
-            float U = dot(R, e2) * sgn;
-            float V = dot(R, e1) * sgn;
-            float T = dot(Ng, Cv) * sgn;
-            if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * tmin < T && T <= absDen * tmax) {
-                // The accept tests run in fp32; the distance that is kept is the same quotient
-                // T/|den| evaluated in fp64 (a few dozen operations on accepted hits only), which
-                // removes the 1e-5-level error fp32 shows on thin, distant triangles.
-                double e1x = (double)p0.x - p1.x, e1y = (double)p0.y - p1.y, e1z = (double)p0.z - p1.z;
-                double e2x = (double)p2.x - p0.x, e2y = (double)p2.y - p0.y, e2z = (double)p2.z - p0.z;
-                double nx_ = e2y * e1z - e2z * e1y, ny_ = e2z * e1x - e2x * e1z, nz_ = e2x * e1y - e2y * e1x;
-                double num = nx_ * ((double)p0.x - o.x) + ny_ * ((double)p0.y - o.y) + nz_ * ((double)p0.z - o.z);
-                double dd = nx_ * d.x + ny_ * d.y + nz_ * d.z;
-                float tr = (float)(num / dd);
-                tmax = (tr > tmin) ? tr : T / absDen;
-                hit = ti;
-            }
-        }
-
-        if ((G.y & 0xff000000u) == 0u) {
-            if (sp == 0) break;
-            sp--;
-            G = (sp < WAPT_LDS_STACK) ? lds[sp * WAPT_BLOCK]
-                                      : m.spill[(size_t)(sp - WAPT_LDS_STACK) * m.spill_stride + glane];
-        }
+    Trav t;
+    trav_begin(t, o, d, tmin, tmax);
+    while (!trav_step<COUNT>(m, t, lds, glane, cnt)) {
     }
-    return hit;
+    tmax = trav_finish(m, t);
+    return t.hit;
+}
+
+// Hands work items to the lanes of one wave.  Wave w of W owns the 64-item blocks w, w+W, w+2W, ...
+// of the queue (the same interleaving a grid-stride loop gives, so every wave sees a sample of the
+// whole queue and the waves finish together); a lane that asks (`want`) gets the next unassigned item
+// of its wave or 0xffffffff.  Must be called by all lanes of the wave together.
+struct WaveFeed {
+    uint32_t next;   // items of this wave handed out so far
+    uint32_t wave, waves, n;
+    __device__ __forceinline__ uint32_t take(bool want) {
+        unsigned long long mk = __ballot(want);
+        uint32_t lane = __lane_id();
+        uint32_t p = next + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+        unsigned long long idx = ((unsigned long long)(p >> 6) * waves + wave) * 64ull + (p & 63u);
+        // stop counting once the wave's blocks are exhausted (keeps `next` from wrapping)
+        if (((unsigned long long)(next >> 6) * waves + wave) * 64ull < n) next += (uint32_t)__popcll(mk);
+        return (want && idx < n) ? (uint32_t)idx : 0xffffffffu;
+    }
+};
+
+__device__ __forceinline__ WaveFeed wave_feed(uint32_t n) {
+    WaveFeed f;
+    f.next = 0;
+    f.waves = (gridDim.x * blockDim.x) >> 6;
+    f.wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    f.n = n;
+    return f;
 }

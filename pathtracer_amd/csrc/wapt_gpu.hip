@@ -227,20 +227,33 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_raygen(KScene sc, KQueues q, KP
     }
 }
 
-// traceFAST for every task of the step (content.cpp:91-123).  COUNT adds node-visit and
-// triangle-test tallies (rays[1], rays[2]) for the bytes-per-ray figure of the roofline.
+// traceFAST for every task of the step (content.cpp:91-123).  Each wave owns a contiguous slice of
+// the step's tasks and streams it through its lanes: a lane whose ray has ended takes the next one.
+// COUNT adds node-visit and triangle-test tallies (rays[1], rays[2]) for the bytes-per-ray figure of
+// the roofline.
 template <bool COUNT>
 __global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int depth, uint32_t start, uint32_t n) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     TraceCount tc = {0, 0, 0, 0};
-    for (uint32_t i = glane; i < n; i += gridDim.x * blockDim.x) {
-        size_t k = (size_t)depth * q.capR + start + i;
-        float4 a = q.RA[k], b = q.RB[k];
-        float tmax = WAPT_TFAR;
-        uint32_t tri = trace_ray<COUNT>(sc.tm, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, tmax,
-                                        &s_stack[threadIdx.x], glane, tc);
-        q.hits[i] = make_uint2(f2u(tmax), tri);
+    WaveFeed feed = wave_feed(n);
+    Trav t;
+    bool have = false;
+    uint32_t cur = 0;
+    const size_t base = (size_t)depth * q.capR + start;
+    for (;;) {
+        uint32_t idx = feed.take(!have);
+        if (idx != 0xffffffffu) {
+            float4 a = q.RA[base + idx], b = q.RB[base + idx];
+            trav_begin(t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, WAPT_TFAR);
+            cur = idx;
+            have = true;
+        }
+        if (!__any(have)) break;
+        if (have && trav_step<COUNT>(sc.tm, t, &s_stack[threadIdx.x], glane, tc)) {
+            q.hits[cur] = make_uint2(f2u(trav_finish(sc.tm, t)), t.hit);
+            have = false;
+        }
     }
     if (COUNT) {
         uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.tris);
@@ -550,7 +563,8 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KP
     }
 }
 
-// visibility() (cpp:693-790): walk from A to B through every surface in between
+// visibility() (cpp:693-790): walk from A to B through every surface in between.  Lanes stream
+// tasks like k_trace; a walk that has to continue past a transparent surface keeps its lane.
 __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,25 +572,44 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
     TraceCount tc = {0, 0, 0, 0};
     uint32_t rays = 0;
     const int global_m = sc.n_objects;
-    for (uint32_t i = glane; i < n; i += gridDim.x * blockDim.x) {
-        float4 a = q.SA[i], b = q.SB[i], w4 = q.SC[i];
-        V3 A = v3(a.x, a.y, a.z), B = v3(b.x, b.y, b.z);
-        uint32_t pixel = f2u(a.w);
-        V3 AB = B - A;
-        float ABl = mag(AB);
-        V3 ABn = (1.0f / ABl) * AB;
-        V3 V = v3(1.f, 1.f, 1.f);
-        V3 P0 = A;
-        float d = 0.f;
-        int cur = global_m;
-        bool lit = false;
-        if (!(ABl > 0.f)) continue;
-        for (int it = 0; it < 4096; it++) {
-            float tmax = WAPT_TFAR;
-            uint32_t tri = trace_ray<false>(sc.tm, P0, ABn, WAPT_TRACE_BIAS, tmax, &s_stack[threadIdx.x], glane, tc);
+    WaveFeed feed = wave_feed(n);
+    Trav t;
+    bool have_task = false, have_ray = false;
+    // walk state (names as in the reference)
+    V3 B = v3(0, 0, 0), ABn = v3(0, 0, 1), V = v3(1, 1, 1), P0 = v3(0, 0, 0), W = v3(0, 0, 0);
+    float ABl = 0.f, d = 0.f;
+    int cur = global_m, it = 0;
+    uint32_t pixel = 0;
+    for (;;) {
+        uint32_t idx = feed.take(!have_task);
+        if (idx != 0xffffffffu) {
+            float4 a = q.SA[idx], b = q.SB[idx], w4 = q.SC[idx];
+            V3 A = v3(a.x, a.y, a.z);
+            B = v3(b.x, b.y, b.z);
+            pixel = f2u(a.w);
+            W = v3(w4.x, w4.y, w4.z);
+            V3 AB = B - A;
+            ABl = mag(AB);
+            ABn = (1.0f / ABl) * AB;
+            V = v3(1.f, 1.f, 1.f);
+            P0 = A;
+            d = 0.f;
+            cur = global_m;
+            it = 0;
+            have_task = ABl > 0.f;
+        }
+        if (have_task && !have_ray) {
+            trav_begin(t, P0, ABn, WAPT_TRACE_BIAS, WAPT_TFAR);
+            have_ray = true;
             rays++;
+        }
+        if (!__any(have_task)) break;
+        if (have_ray && trav_step<false>(sc.tm, t, &s_stack[threadIdx.x], glane, tc)) {
+            have_ray = false;
+            float tmax = trav_finish(sc.tm, t);
+            uint32_t tri = t.hit;
             V3 P1;
-            bool entering = false, opaque = false;
+            bool entering = false, opaque = false, blocked = false, lit = false;
             int obj = -1;
             V3 hp = point_at(P0, tmax, ABn);
             if (tri != 0xffffffffu) d += mag(hp - P0);
@@ -591,7 +624,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
                 if (entering) {
                     cur = global_m;
                     // glass blocks shadow walks outright (cpp:757-759)
-                    if ((m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) && m.ior > 1.0f) break;
+                    blocked = (m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) && m.ior > 1.0f;
                 } else {
                     cur = obj;
                 }
@@ -599,18 +632,22 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
                 P1 = B;
                 d = ABl;
             }
-            V = V * attenuation(sc.mats[cur], mag(P1 - P0));
-            if (d >= ABl - WAPT_TRACE_BIAS) {
-                lit = true;
-                break;
+            if (!blocked) {
+                V = V * attenuation(sc.mats[cur], mag(P1 - P0));
+                if (d >= ABl - WAPT_TRACE_BIAS) lit = true;
+                else if (opaque) blocked = true;
+                else if (V.x < WAPT_LOW_VIS && V.y < WAPT_LOW_VIS && V.z < WAPT_LOW_VIS) blocked = true;
             }
-            if (opaque) break;
-            if (V.x < WAPT_LOW_VIS && V.y < WAPT_LOW_VIS && V.z < WAPT_LOW_VIS) break;
-            P0 = P1;
-            cur = entering ? obj : global_m;
+            if (!blocked && !lit && ++it >= 4096) blocked = true;
+            if (lit || blocked) {
+                DBG(pixel, "shadow B=(%.5f %.5f %.5f) lit=%d V=%g w=%g d=%.6f ABl=%.6f\n", B.x, B.y, B.z, (int)lit, V.x, W.x, d, ABl);
+                if (lit) add_rgb(q.sum, pixel, W * V);
+                have_task = false;
+            } else {
+                P0 = P1;
+                cur = entering ? obj : global_m;
+            }
         }
-        DBG(pixel, "shadow A=(%.5f %.5f %.5f) B=(%.5f %.5f %.5f) lit=%d V=%g w=%g d=%.6f ABl=%.6f\n", A.x, A.y, A.z, B.x, B.y, B.z, (int)lit, V.x, w4.x, d, ABl);
-        if (lit) add_rgb(q.sum, pixel, v3(w4.x, w4.y, w4.z) * V);
     }
     rays = wave_sum(rays);
     if (lane_id() == 0 && rays) atomicAdd(q.rays, (unsigned long long)rays);
@@ -678,25 +715,36 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const flo
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     TraceCount tc = {0, 0, 0, 0};
-    for (uint32_t i = glane; i < n; i += gridDim.x * blockDim.x) {
-        float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
-        float tmax = b.w;
-        uint32_t tri = trace_ray<COUNT>(tm, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, &s_stack[threadIdx.x], glane, tc);
-        float* h = hits + 6 * (size_t)i;
-        if (tri == 0xffffffffu) {
-            h[0] = tmax;
-            h[1] = u2f(0xffffffffu);
-            h[2] = u2f(0xffffffffu);
-            h[3] = h[4] = h[5] = 0.f;
-        } else {
-            int obj, prim;
-            V3 Ng = tri_normal(tm.tris, tri, &obj, &prim);
-            h[0] = tmax;
-            h[1] = u2f((uint32_t)prim);
-            h[2] = u2f((uint32_t)obj);
-            h[3] = Ng.x;
-            h[4] = Ng.y;
-            h[5] = Ng.z;
+    WaveFeed feed = wave_feed(n);
+    Trav t;
+    bool have = false;
+    uint32_t cur = 0;
+    for (;;) {
+        uint32_t idx = feed.take(!have);
+        if (idx != 0xffffffffu) {
+            float4 a = rays[2 * (size_t)idx], b = rays[2 * (size_t)idx + 1];
+            trav_begin(t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, b.w);
+            cur = idx;
+            have = true;
+        }
+        if (!__any(have)) break;
+        if (have && trav_step<COUNT>(tm, t, &s_stack[threadIdx.x], glane, tc)) {
+            have = false;
+            float* h = hits + 6 * (size_t)cur;
+            h[0] = trav_finish(tm, t);
+            if (t.hit == 0xffffffffu) {
+                h[1] = u2f(0xffffffffu);
+                h[2] = u2f(0xffffffffu);
+                h[3] = h[4] = h[5] = 0.f;
+            } else {
+                int obj, prim;
+                V3 Ng = tri_normal(tm.tris, t.hit, &obj, &prim);
+                h[1] = u2f((uint32_t)prim);
+                h[2] = u2f((uint32_t)obj);
+                h[3] = Ng.x;
+                h[4] = Ng.y;
+                h[5] = Ng.z;
+            }
         }
     }
     if (COUNT) {
