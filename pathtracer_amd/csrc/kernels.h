@@ -28,8 +28,9 @@ enum {
     CNT_S,        // shadow-walk tasks
     CNT_P,        // probe tasks
     CNT_OVERFLOW, // traversal pushes dropped + queue pushes dropped (must stay 0)
+    CNT_FEED = 128, // 2 x 32 work-feed counters of k_trace and k_shadow, 64 words apart (zeroed by k_reset)
     CNT_R0 = 8,   // CNT_R0 + d: tasks in R[d]
-    CNT_TOTAL = 8 + 64
+    CNT_TOTAL = 128 + 2 * 32 * 64
 };
 
 enum { RAY_CAMERA = 0, RAY_DIFFUSE = 1, RAY_SPECULAR = 2 };  // unidirectionalPathTracer.h:9-11

@@ -25,7 +25,8 @@ struct TraceMem {
     const uint4* __restrict__ nodes;   // 5 x uint4 per node
     const float4* __restrict__ tris;   // 3 x float4 per triangle
     uint2* spill;
-    uint32_t spill_stride;             // lanes of the launch (grid*block)
+    uint32_t spill_stride;             // lanes of the largest launch
+    int32_t stack_cap;                 // WAPT_LDS_STACK + spill entries per lane (>= depth of the tree)
 };
 
 struct TraceCount {
@@ -93,6 +94,7 @@ struct Trav {
     uint32_t hit;   // triangle index or 0xffffffff
     uint2 G;        // current node group
     int sp;
+    float tblock;   // shadow walks: an OPAQUE surface hit closer than this ends the search at once
 };
 
 __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, float tmax) {
@@ -108,13 +110,17 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
     t.hit = 0xffffffffu;
     t.G = make_uint2(0u, 0x80000000u);  // root: "child 0 of group 0 is pending"
     t.sp = 0;
+    t.tblock = 0.f;
 }
 
 // One traversal step: visit the nearest pending inner child (if any), test the triangles of the
 // leaves that node exposes, pop when the current group is exhausted.  Returns true when the ray is
 // finished.  `lds` points at this lane's column of the block's short stack (element stride
 // WAPT_BLOCK), `glane` is the lane's index in the launch.
-template <bool COUNT>
+// SHADOW: the caller only wants to know what a shadow walk needs, so the search stops at the first
+// opaque triangle (bit 0 of the triangle record's last word) closer than t.tblock: whatever else lies
+// in front of it, the walk from A to B ends with zero visibility.
+template <bool COUNT, bool SHADOW = false>
 __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, uint2* lds, uint32_t glane, TraceCount& cnt) {
     const bool nx = t.d.x < 0.f, ny = t.d.y < 0.f, nz = t.d.z < 0.f;
     uint2 T;
@@ -126,7 +132,7 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, uint2* lds
             if (t.sp < WAPT_LDS_STACK) {
                 lds[t.sp * WAPT_BLOCK] = t.G;
                 t.sp++;
-            } else if (t.sp < WAPT_STACK_CAP) {
+            } else if (t.sp < m.stack_cap) {
                 m.spill[(size_t)(t.sp - WAPT_LDS_STACK) * m.spill_stride + glane] = t.G;
                 t.sp++;
                 if (COUNT) cnt.spills++;
@@ -188,8 +194,13 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, uint2* lds
         float V = dot(R, e1) * sgn;
         float Tn = dot(Ng, Cv) * sgn;
         if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * t.tmin < Tn && Tn <= absDen * t.tmax) {
-            t.tmax = __fdividef(Tn, absDen);  // fp32 while searching, like Embree; see trav_finish
+            t.tmax = __fdividef(Tn, absDen);  // fp32 while searching, like Embree; see refine_distance
             t.hit = ti;
+            if (SHADOW && (__float_as_uint(c.w) & 1u) && Tn < absDen * t.tblock) {
+                t.G = make_uint2(0u, 0u);
+                t.sp = 0;
+                T.y = 0u;
+            }
         }
     }
 
@@ -202,20 +213,26 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, uint2* lds
     return false;
 }
 
-// Distance of the final hit: the same quotient T/|den| as in the search, re-evaluated in fp64 from
-// the float vertices (fp32 shows 1e-5-level relative error on thin, distant triangles; the
-// acceptance bar for hit distances is 1e-5).  Returns the distance (t.tmax on a miss).
-__device__ __forceinline__ float trav_finish(const TraceMem& m, const Trav& t) {
-    if (t.hit == 0xffffffffu) return t.tmax;
-    const float4* tp = m.tris + (size_t)t.hit * 3;
+// Distance of a hit: the same quotient T/|den| as in the search, re-evaluated in fp64 from the float
+// vertices (fp32 shows 1e-5-level relative error on thin, distant triangles; the acceptance bar for
+// hit distances is 1e-5).  `t32` is the fp32 distance the search produced (returned if the fp64 value
+// falls out of the interval by rounding).
+__device__ __forceinline__ float refine_distance(const float4* __restrict__ tris, uint32_t tri, V3 o, V3 d, float tmin,
+                                                 float t32) {
+    const float4* tp = tris + (size_t)tri * 3;
     float4 a = tp[0], b = tp[1], c = tp[2];
     double e1x = (double)a.x - a.w, e1y = (double)a.y - b.x, e1z = (double)a.z - b.y;
     double e2x = (double)b.z - a.x, e2y = (double)b.w - a.y, e2z = (double)c.x - a.z;
     double nx_ = e2y * e1z - e2z * e1y, ny_ = e2z * e1x - e2x * e1z, nz_ = e2x * e1y - e2y * e1x;
-    double num = nx_ * ((double)a.x - t.o.x) + ny_ * ((double)a.y - t.o.y) + nz_ * ((double)a.z - t.o.z);
-    double dd = nx_ * t.d.x + ny_ * t.d.y + nz_ * t.d.z;
+    double num = nx_ * ((double)a.x - o.x) + ny_ * ((double)a.y - o.y) + nz_ * ((double)a.z - o.z);
+    double dd = nx_ * d.x + ny_ * d.y + nz_ * d.z;
     float tr = (float)(num / dd);
-    return (tr > t.tmin) ? tr : t.tmax;
+    return (tr > tmin) ? tr : t32;
+}
+
+__device__ __forceinline__ float trav_finish(const TraceMem& m, const Trav& t) {
+    if (t.hit == 0xffffffffu) return t.tmax;
+    return refine_distance(m.tris, t.hit, t.o, t.d, t.tmin, t.tmax);
 }
 
 // Traces one ray to completion (kernels whose lanes do not stream rays).  On return tmax is the hit
@@ -231,29 +248,55 @@ __device__ __forceinline__ uint32_t trace_ray(const TraceMem& m, V3 o, V3 d, flo
     return t.hit;
 }
 
-// Hands work items to the lanes of one wave.  Wave w of W owns the 64-item blocks w, w+W, w+2W, ...
-// of the queue (the same interleaving a grid-stride loop gives, so every wave sees a sample of the
-// whole queue and the waves finish together); a lane that asks (`want`) gets the next unassigned item
-// of its wave or 0xffffffff.  Must be called by all lanes of the wave together.
+// Hands work items to the lanes of one wave of a persistent launch.  The queue is dealt out in groups
+// of 64 consecutive items; group g belongs to shard g % WAPT_FEED_SHARDS, every shard has a counter
+// of its own, and a wave whose current group is used up draws the next group of the shard its block
+// maps to (one returning atomic per 64 items, spread over 32 counters).  The cost of a ray varies by
+// more than 10x (wall vs. mesh): with a fixed share per wave the average wave was resident for 43 % of
+// the kernel's duration, with groups drawn on demand the waves finish together.  Neighbouring groups
+// are in flight at the same time, which keeps the BVH lines they touch in L1/L2.
+// A lane that asks (`want`) gets the next unassigned item or 0xffffffff; take() must be called by all
+// lanes of the wave together, and the counters must be zero when the kernel starts.
+#define WAPT_FEED_SHARDS 32
+#define WAPT_FEED_STRIDE 64
 struct WaveFeed {
-    uint32_t next;   // items of this wave handed out so far
-    uint32_t wave, waves, n;
+    uint32_t next, end;   // unassigned part of the current group
+    uint32_t n, shard;
+    uint32_t* counter;
+    bool dry;
     __device__ __forceinline__ uint32_t take(bool want) {
         unsigned long long mk = __ballot(want);
+        if (mk == 0ull) return 0xffffffffu;
+        if (next >= end && !dry) {
+            uint32_t k = 0;
+            if (__lane_id() == 0) k = atomicAdd(counter, 1u);
+            k = (uint32_t)__shfl((int)k, 0);
+            unsigned long long b = ((unsigned long long)k * WAPT_FEED_SHARDS + shard) * 64ull;
+            if (b >= n) {
+                dry = true;
+            } else {
+                next = (uint32_t)b;
+                end = (b + 64ull < n) ? (uint32_t)(b + 64ull) : n;
+            }
+        }
         uint32_t lane = __lane_id();
-        uint32_t p = next + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
-        unsigned long long idx = ((unsigned long long)(p >> 6) * waves + wave) * 64ull + (p & 63u);
-        // stop counting once the wave's blocks are exhausted (keeps `next` from wrapping)
-        if (((unsigned long long)(next >> 6) * waves + wave) * 64ull < n) next += (uint32_t)__popcll(mk);
-        return (want && idx < n) ? (uint32_t)idx : 0xffffffffu;
+        uint32_t idx = next + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+        uint32_t got = (want && idx < end) ? idx : 0xffffffffu;
+        uint32_t c = (uint32_t)__popcll(mk);
+        next = (end - next < c) ? end : next + c;
+        return got;
     }
 };
 
-__device__ __forceinline__ WaveFeed wave_feed(uint32_t n) {
+__device__ __forceinline__ WaveFeed wave_feed(uint32_t n, uint32_t* counters) {
     WaveFeed f;
-    f.next = 0;
-    f.waves = (gridDim.x * blockDim.x) >> 6;
-    f.wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    f.shard = blockIdx.x % WAPT_FEED_SHARDS;
     f.n = n;
+    f.counter = counters + f.shard * WAPT_FEED_STRIDE;  // one 256-byte line per counter: atomics on words of
+                                                        // one line queue behind each other like atomics on one word
+    f.next = f.end = 0;
+    f.dry = n == 0;
     return f;
 }
+
+static inline uint32_t feed_blocks(uint64_t n) { return (uint32_t)((n + 1023) / 1024); }

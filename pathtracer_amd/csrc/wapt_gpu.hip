@@ -195,6 +195,7 @@ __device__ __forceinline__ V3 surface_weight(const KScene& sc, const HitCtx& c) 
 __global__ void k_reset(uint32_t* cnt, int r_slot, uint32_t r_value) {
     uint32_t t = threadIdx.x;
     if (t <= CNT_P) cnt[t] = 0u;
+    cnt[CNT_FEED + t * WAPT_FEED_STRIDE] = 0u;  // 64 threads, 64 feed counters
     if (r_slot >= 0 && t == 0) cnt[r_slot] = r_value;
 }
 
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int 
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     TraceCount tc = {0, 0, 0, 0};
-    WaveFeed feed = wave_feed(n);
+    WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED);
     Trav t;
     bool have = false;
     uint32_t cur = 0;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int 
         }
         if (!__any(have)) break;
         if (have && trav_step<COUNT>(sc.tm, t, &s_stack[threadIdx.x], glane, tc)) {
-            q.hits[cur] = make_uint2(f2u(trav_finish(sc.tm, t)), t.hit);
+            q.hits[cur] = make_uint2(f2u(t.tmax), t.hit);  // fp32 distance; k_head refines it
             have = false;
         }
     }
@@ -273,6 +274,15 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_head(KScene sc, KQueues q, KPar
         if (valid) {
             HitCtx c = {};
             load_task(q, depth, start, i, c);
+            {
+                // the closest-hit kernel leaves the fp32 distance of its search; the fp64 re-evaluation runs
+                // here, where every lane has a hit to refine, and is written back for the shading kernels
+                uint2 h = q.hits[i];
+                if (h.y != 0xffffffffu) {
+                    float tr = refine_distance(sc.tm.tris, h.y, c.o, c.dir, WAPT_TRACE_BIAS, u2f(h.x));
+                    q.hits[i] = make_uint2(f2u(tr), h.y);
+                }
+            }
             load_hit(sc, q, i, c);
             DBG(c.pixel, "head d=%d key=%08x o=(%.6f %.6f %.6f) dir=(%.7f %.7f %.7f) t=%.6f tri=%u P=(%.6f %.6f %.6f) obj=%d beta=%g\n", depth, c.key, c.o.x, c.o.y, c.o.z, c.dir.x, c.dir.y, c.dir.z, c.t, c.tri, c.P.x, c.P.y, c.P.z, c.obj, c.beta.x);
             if (c.tri == 0xffffffffu) {
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
     TraceCount tc = {0, 0, 0, 0};
     uint32_t rays = 0;
     const int global_m = sc.n_objects;
-    WaveFeed feed = wave_feed(n);
+    WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED + 32 * WAPT_FEED_STRIDE);
     Trav t;
     bool have_task = false, have_ray = false;
     // walk state (names as in the reference)
@@ -599,15 +609,29 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
             have_task = ABl > 0.f;
         }
         if (have_task && !have_ray) {
-            trav_begin(t, P0, ABn, WAPT_TRACE_BIAS, WAPT_TFAR);
+            // Nothing beyond B matters (a hit there and a miss are treated alike, cpp:764-769) and an opaque
+            // surface clearly before B ends the walk with zero visibility whatever else is in between
+            // (cpp:778), so the search is cut at B and stops at the first such surface.  The margins cover
+            // the fp32 error of search distances (about 2e-5 relative); the walk's own tests below use the
+            // refined distance and the reference's thresholds.
+            float rest = ABl - d, margin = 0.002f + 1e-4f * ABl;
+            trav_begin(t, P0, ABn, WAPT_TRACE_BIAS, rest + margin);
+            t.tblock = rest - margin;
             have_ray = true;
             rays++;
         }
         if (!__any(have_task)) break;
-        if (have_ray && trav_step<false>(sc.tm, t, &s_stack[threadIdx.x], glane, tc)) {
+        if (have_ray && trav_step<false, true>(sc.tm, t, &s_stack[threadIdx.x], glane, tc)) {
             have_ray = false;
-            float tmax = trav_finish(sc.tm, t);
+            float tmax = t.tmax;
             uint32_t tri = t.hit;
+            if (tri != 0xffffffffu) {
+                // fp32 search distances are good to about 2e-5 relative; the walk's decisions compare the
+                // distance with |AB| +- 0.001, so a hit clearly beyond B needs no better value (B itself is
+                // used); one before or near B gets the fp64 distance (it may seed the next segment)
+                float dd32 = d + tmax;
+                if (!(dd32 > ABl + (0.002f + 5e-5f * ABl))) tmax = refine_distance(sc.tm.tris, tri, t.o, t.d, t.tmin, tmax);
+            }
             V3 P1;
             bool entering = false, opaque = false, blocked = false, lit = false;
             int obj = -1;
@@ -711,11 +735,11 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
 // Batch closest-hit for wapt_intersect*
 template <bool COUNT>
 __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const float4* rays, uint32_t n, float* hits,
-                                                          unsigned long long* counters) {
+                                                          unsigned long long* counters, uint32_t* feed_counters) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     TraceCount tc = {0, 0, 0, 0};
-    WaveFeed feed = wave_feed(n);
+    WaveFeed feed = wave_feed(n, feed_counters);
     Trav t;
     bool have = false;
     uint32_t cur = 0;
@@ -937,6 +961,8 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     s->n_tris = bvh.tris.size();
     s->bvh_depth = bvh.max_depth;
     s->sah = bvh.sah_cost;
+    // bit 0 of a triangle's last word: its object is opaque (lets shadow walks stop at the first such hit)
+    for (auto& T : bvh.tris) T.pad = (desc->materials[T.obj].flags & WAPT_MAT_OPAQUE) ? 1u : 0u;
     HIPCHK_S(hipMalloc(&s->d_nodes, bvh.nodes.size() * sizeof(Bvh8Node)));
     HIPCHK_S(hipMalloc(&s->d_tris, bvh.tris.size() * sizeof(Bvh8Tri)));
     HIPCHK_S(hipMemcpy(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice));
@@ -981,8 +1007,6 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     HIPCHK_S(hipGetDeviceProperties(&prop, device));
     uint32_t cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
     s->grid = cus * env_u32("WAPT_BLOCKS_PER_CU", 6);
-    size_t spill_entries = (size_t)(WAPT_STACK_CAP - WAPT_LDS_STACK) * s->grid * WAPT_BLOCK;
-    HIPCHK_S(hipMalloc(&s->d_spill, spill_entries * sizeof(uint2)));
     HIPCHK_S(hipMalloc((void**)&s->d_cnt, CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK_S(hipMemset(s->d_cnt, 0, CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK_S(hipMalloc((void**)&s->d_rays, 4 * sizeof(unsigned long long)));
@@ -992,8 +1016,9 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     memset(&s->ks, 0, sizeof(s->ks));
     s->ks.tm.nodes = (const uint4*)s->d_nodes;
     s->ks.tm.tris = (const float4*)s->d_tris;
-    s->ks.tm.spill = (uint2*)s->d_spill;
-    s->ks.tm.spill_stride = s->grid * WAPT_BLOCK;
+    s->ks.tm.spill = nullptr;  // allocated with the queues (ensure_spill)
+    s->ks.tm.spill_stride = 0;
+    s->ks.tm.stack_cap = WAPT_LDS_STACK;
     s->ks.mats = (const DMaterial*)s->d_mats;
     s->ks.lights = (const DLight*)s->d_lights;
     s->ks.n_lights = desc->n_lights;
@@ -1040,6 +1065,22 @@ extern "C" int wapt_scene_bvh_info(const wapt_scene* s, wapt_bvh_info* o) {
 }
 
 namespace {
+
+// Spill area of the traversal stacks: (tree depth - LDS entries) slots for every lane of the largest launch.
+int ensure_spill(wapt_scene* s, uint64_t max_items) {
+    uint32_t blocks = std::max(feed_blocks(max_items), s->grid);
+    uint32_t lanes = blocks * WAPT_BLOCK;
+    if (s->d_spill && s->ks.tm.spill_stride >= lanes) return WAPT_OK;
+    if (s->d_spill) HIPCHK(hipFree(s->d_spill));
+    s->d_spill = nullptr;
+    int depth_slots = std::max(1, (int)s->bvh_depth + 1 - WAPT_LDS_STACK);
+    depth_slots = std::min(depth_slots, WAPT_STACK_CAP - WAPT_LDS_STACK);
+    HIPCHK(hipMalloc(&s->d_spill, (size_t)depth_slots * lanes * sizeof(uint2)));
+    s->ks.tm.spill = (uint2*)s->d_spill;
+    s->ks.tm.spill_stride = lanes;
+    s->ks.tm.stack_cap = WAPT_LDS_STACK + depth_slots;
+    return WAPT_OK;
+}
 
 // (Re)allocates the work queues for a trace depth.
 int ensure_queues(wapt_scene* s, int td) {
@@ -1092,7 +1133,7 @@ int ensure_queues(wapt_scene* s, int td) {
     s->capP = capP;
     s->queue_bytes = bytes;
     s->queue_depths = depths;
-    return WAPT_OK;
+    return ensure_spill(s, std::max<uint64_t>(capR, std::max(capS, capP)));
 }
 
 struct Timer {
@@ -1205,7 +1246,7 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
             if (kp.dense_raygen) {
                 have[0] = n;
             } else {
-                HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 have[0] = std::min(s->h_cnt[CNT_R0], s->capR);
             }
@@ -1231,16 +1272,18 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
             tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_volume, sgrid, sblock, 0, st, ks, q, kp, d, start); });
             tm.run(FAM_PROBE, [&] { hipLaunchKernelGGL(k_probe, grid, block, 0, st, ks, q); });
         }
-        tm.run(FAM_SHADOW, [&] { hipLaunchKernelGGL(k_shadow, grid, block, 0, st, ks, q); });
+        {
+            tm.run(FAM_SHADOW, [&] { hipLaunchKernelGGL(k_shadow, grid, block, 0, st, ks, q); });
+        }
         n_shadow_launches++;
         if (d < td) {
-            HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             have[d + 1] = std::min(s->h_cnt[CNT_R0 + d + 1], s->capR);
         }
     }
     unsigned long long h_rays[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_TOTAL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(h_rays, s->d_rays, sizeof(h_rays), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
@@ -1315,13 +1358,21 @@ extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint
         HIPCHK(hipEventCreate(&b));
         HIPCHK(hipEventRecord(a, s->stream));
     }
-    if (n) {
-        if (counters)
-            hipLaunchKernelGGL(k_intersect<true>, dim3(s->grid), dim3(WAPT_BLOCK), 0, s->stream, s->ks.tm,
-                               (const float4*)d_rays, n, (float*)d_hits, s->d_rays);
-        else
-            hipLaunchKernelGGL(k_intersect<false>, dim3(s->grid), dim3(WAPT_BLOCK), 0, s->stream, s->ks.tm,
-                               (const float4*)d_rays, n, (float*)d_hits, s->d_rays);
+    {
+        // batches of at most 2^22 rays keep the stack spill area small
+        const uint32_t batch = 1u << 22;
+        int rc = ensure_spill(s, batch);
+        if (rc) return rc;
+        for (uint64_t off = 0; off < n; off += batch) {
+            uint32_t m = (uint32_t)std::min<uint64_t>(batch, n - off);
+            hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s->stream, s->d_cnt, -1, 0u);
+            const float4* r = (const float4*)d_rays + 2 * off;
+            float* h = (float*)d_hits + 6 * off;
+            if (counters)
+                hipLaunchKernelGGL(k_intersect<true>, dim3(s->grid), dim3(WAPT_BLOCK), 0, s->stream, s->ks.tm, r, m, h, s->d_rays, s->d_cnt + CNT_FEED);
+            else
+                hipLaunchKernelGGL(k_intersect<false>, dim3(s->grid), dim3(WAPT_BLOCK), 0, s->stream, s->ks.tm, r, m, h, s->d_rays, s->d_cnt + CNT_FEED);
+        }
     }
     if (ms) HIPCHK(hipEventRecord(b, s->stream));
     unsigned long long h[4] = {0, 0, 0, 0};
