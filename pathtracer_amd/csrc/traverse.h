@@ -27,6 +27,7 @@ struct TraceMem {
     uint2* spill;
     uint32_t spill_stride;             // lanes of the largest launch
     int32_t stack_cap;                 // WAPT_LDS_STACK + spill entries per lane (>= depth of the tree)
+    int32_t tri_quorum;                // lanes with pending triangles that trigger the triangle loop
 };
 
 struct TraceCount {
@@ -93,6 +94,7 @@ struct Trav {
     uint32_t octinv;
     uint32_t hit;   // triangle index or 0xffffffff
     uint2 G;        // current node group
+    uint2 T;        // pending triangles: first index, hit bits
     int sp;
     float tblock;   // shadow walks: an OPAQUE surface hit closer than this ends the search at once
 };
@@ -109,22 +111,37 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
     t.octinv = (d.x < 0.f ? 0u : 4u) | (d.y < 0.f ? 0u : 2u) | (d.z < 0.f ? 0u : 1u);
     t.hit = 0xffffffffu;
     t.G = make_uint2(0u, 0x80000000u);  // root: "child 0 of group 0 is pending"
+    t.T = make_uint2(0u, 0u);
     t.sp = 0;
     t.tblock = 0.f;
 }
 
-// One traversal step: visit the nearest pending inner child (if any), test the triangles of the
-// leaves that node exposes, pop when the current group is exhausted.  Returns true when the ray is
-// finished.  `lds` points at this lane's column of the block's short stack (element stride
-// WAPT_BLOCK), `glane` is the lane's index in the launch.
+// One traversal step of a wave.  A lane without pending triangles visits its nearest pending inner
+// child (popping the stack when its current group is exhausted); triangles that the visited nodes
+// expose are collected in t.T and tested when at least `tri_quorum` lanes of the wave have some or no
+// lane can descend any further.  (Measured on the dragon scene: postponing the triangle loop to gather
+// more lanes loses more to waiting than it saves - closest-hit kernel 11.8 / 12.8 / 14.4 / 15.7 ms per
+// frame at quorum 1 / 8 / 32 / 48 - so the default quorum is 1; the knob stays.)  Returns true when the lane's
+// ray is finished.  Must be called by all lanes of the wave together (`have` = lane holds a ray).
+// `lds` points at this lane's column of the block's short stack (element stride WAPT_BLOCK), `glane`
+// is the lane's index in the launch.
 // SHADOW: the caller only wants to know what a shadow walk needs, so the search stops at the first
 // opaque triangle (bit 0 of the triangle record's last word) closer than t.tblock: whatever else lies
 // in front of it, the walk from A to B ends with zero visibility.
 template <bool COUNT, bool SHADOW = false>
-__device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, uint2* lds, uint32_t glane, TraceCount& cnt) {
-    const bool nx = t.d.x < 0.f, ny = t.d.y < 0.f, nz = t.d.z < 0.f;
-    uint2 T;
-    if (t.G.y & 0xff000000u) {
+__device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have, uint2* lds, uint32_t glane,
+                                          TraceCount& cnt) {
+    const int tri_quorum = m.tri_quorum;
+    bool descend = have && t.T.y == 0u;
+    if (descend && (t.G.y & 0xff000000u) == 0u) {
+        // current group exhausted: pop, or finish
+        if (t.sp == 0) return true;
+        t.sp--;
+        t.G = (t.sp < WAPT_LDS_STACK) ? lds[t.sp * WAPT_BLOCK]
+                                      : m.spill[(size_t)(t.sp - WAPT_LDS_STACK) * m.spill_stride + glane];
+    }
+    if (descend) {
+        const bool nx = t.d.x < 0.f, ny = t.d.y < 0.f, nz = t.d.z < 0.f;
         uint32_t hits_imask = t.G.y;
         uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
         t.G.y &= ~(1u << bit);
@@ -164,53 +181,53 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, uint2* lds
         uint32_t hm = hit4(lx0, ly0, lz0, hx0, hy0, hz0, n1.z, ax, ay, az, ox, oy, oz, t.tmin, t.tmax, octinv4);
         hm |= hit4(lx1, ly1, lz1, hx1, hy1, hz1, n1.w, ax, ay, az, ox, oy, oz, t.tmin, t.tmax, octinv4);
         t.G = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
-        T = make_uint2(n1.y, hm & 0x00ffffffu);
-    } else {
-        T = t.G;
-        t.G = make_uint2(0u, 0u);
+        t.T = make_uint2(n1.y, hm & 0x00ffffffu);
     }
 
-    while (T.y) {
-        uint32_t k = (uint32_t)__ffs((int)T.y) - 1u;
-        T.y &= T.y - 1u;
-        uint32_t ti = T.x + k;
-        const float4* tp = m.tris + (size_t)ti * 3;
-        float4 a = tp[0], b = tp[1], c = tp[2];
-        if (COUNT) cnt.tris++;
-        // Ray/triangle test in the form Embree 3 uses for its default (non-robust) triangle
-        // intersector (kernels/geometry/triangle_intersector_moeller.h, Moeller-Trumbore with
-        // C = v0 - org, R = C x D, unnormalised edge tests against |den|): the reference's
-        // closest hits come from that code (src/content.cpp:97), so its edge behaviour is the
-        // one to follow.  Two-sided, interval (tmin, tmax].
-        V3 p0 = v3(a.x, a.y, a.z), p1 = v3(a.w, b.x, b.y), p2 = v3(b.z, b.w, c.x);
-        V3 e1 = p0 - p1, e2 = p2 - p0;
-        V3 Ng = cross(e2, e1);
-        V3 Cv = p0 - t.o;
-        V3 R = cross(Cv, t.d);
-        float den = dot(Ng, t.d);
-        float absDen = fabsf(den);
-        float sgn = den < 0.f ? -1.0f : 1.0f;
-        float U = dot(R, e2) * sgn;
-        float V = dot(R, e1) * sgn;
-        float Tn = dot(Ng, Cv) * sgn;
-        if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * t.tmin < Tn && Tn <= absDen * t.tmax) {
-            t.tmax = __fdividef(Tn, absDen);  // fp32 while searching, like Embree; see refine_distance
-            t.hit = ti;
-            if (SHADOW && (__float_as_uint(c.w) & 1u) && Tn < absDen * t.tblock) {
-                t.G = make_uint2(0u, 0u);
-                t.sp = 0;
-                T.y = 0u;
+    // triangles: now, or with more company later
+    bool pending = have && t.T.y != 0u;
+    bool can_descend = have && t.T.y == 0u && ((t.G.y & 0xff000000u) != 0u || t.sp > 0);
+    int waiting = (int)__popcll(__ballot(pending));
+    if (waiting >= tri_quorum || (waiting > 0 && !__any(can_descend))) {
+        // (lanes without a ray, whose state is stale, stay out: `bits` is zero for them)
+        uint32_t bits = pending ? t.T.y : 0u;
+        while (bits) {
+            uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            uint32_t ti = t.T.x + k;
+            const float4* tp = m.tris + (size_t)ti * 3;
+            float4 a = tp[0], b = tp[1], c = tp[2];
+            if (COUNT) cnt.tris++;
+            // Ray/triangle test in the form Embree 3 uses for its default (non-robust) triangle
+            // intersector (kernels/geometry/triangle_intersector_moeller.h, Moeller-Trumbore with
+            // C = v0 - org, R = C x D, unnormalised edge tests against |den|): the reference's
+            // closest hits come from that code (src/content.cpp:97), so its edge behaviour is the
+            // one to follow.  Two-sided, interval (tmin, tmax].
+            V3 p0 = v3(a.x, a.y, a.z), p1 = v3(a.w, b.x, b.y), p2 = v3(b.z, b.w, c.x);
+            V3 e1 = p0 - p1, e2 = p2 - p0;
+            V3 Ng = cross(e2, e1);
+            V3 Cv = p0 - t.o;
+            V3 R = cross(Cv, t.d);
+            float den = dot(Ng, t.d);
+            float absDen = fabsf(den);
+            float sgn = den < 0.f ? -1.0f : 1.0f;
+            float U = dot(R, e2) * sgn;
+            float V = dot(R, e1) * sgn;
+            float Tn = dot(Ng, Cv) * sgn;
+            if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * t.tmin < Tn && Tn <= absDen * t.tmax) {
+                t.tmax = __fdividef(Tn, absDen);  // fp32 while searching, like Embree; see refine_distance
+                t.hit = ti;
+                if (SHADOW && (__float_as_uint(c.w) & 1u) && Tn < absDen * t.tblock) {
+                    t.G = make_uint2(0u, 0u);
+                    t.sp = 0;
+                    bits = 0u;
+                }
             }
         }
+        if (pending) t.T.y = 0u;
     }
-
-    if ((t.G.y & 0xff000000u) == 0u) {
-        if (t.sp == 0) return true;
-        t.sp--;
-        t.G = (t.sp < WAPT_LDS_STACK) ? lds[t.sp * WAPT_BLOCK]
-                                      : m.spill[(size_t)(t.sp - WAPT_LDS_STACK) * m.spill_stride + glane];
-    }
-    return false;
+    // a lane is finished when nothing is pending anywhere
+    return have && t.T.y == 0u && (t.G.y & 0xff000000u) == 0u && t.sp == 0;
 }
 
 // Distance of a hit: the same quotient T/|den| as in the search, re-evaluated in fp64 from the float
@@ -240,9 +257,13 @@ __device__ __forceinline__ float trav_finish(const TraceMem& m, const Trav& t) {
 template <bool COUNT>
 __device__ __forceinline__ uint32_t trace_ray(const TraceMem& m, V3 o, V3 d, float tmin, float& tmax, uint2* lds,
                                               uint32_t glane, TraceCount& cnt) {
+    // (lanes of a wave may arrive here with different trip counts: keep every lane in the loop until
+    //  the whole wave is done, as trav_step votes across the wave)
     Trav t;
     trav_begin(t, o, d, tmin, tmax);
-    while (!trav_step<COUNT>(m, t, lds, glane, cnt)) {
+    bool have = true;
+    while (__any(have)) {
+        if (trav_step<COUNT>(m, t, have, lds, glane, cnt)) have = false;
     }
     tmax = trav_finish(m, t);
     return t.hit;

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int 
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     TraceCount tc = {0, 0, 0, 0};
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED);
-    Trav t;
+    Trav t = {};
     bool have = false;
     uint32_t cur = 0;
     const size_t base = (size_t)depth * q.capR + start;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int 
             have = true;
         }
         if (!__any(have)) break;
-        if (have && trav_step<COUNT>(sc.tm, t, &s_stack[threadIdx.x], glane, tc)) {
+        if (trav_step<COUNT>(sc.tm, t, have, &s_stack[threadIdx.x], glane, tc)) {
             q.hits[cur] = make_uint2(f2u(t.tmax), t.hit);  // fp32 distance; k_head refines it
             have = false;
         }
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
     uint32_t rays = 0;
     const int global_m = sc.n_objects;
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED + 32 * WAPT_FEED_STRIDE);
-    Trav t;
+    Trav t = {};
     bool have_task = false, have_ray = false;
     // walk state (names as in the reference)
     V3 B = v3(0, 0, 0), ABn = v3(0, 0, 1), V = v3(1, 1, 1), P0 = v3(0, 0, 0), W = v3(0, 0, 0);
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
             rays++;
         }
         if (!__any(have_task)) break;
-        if (have_ray && trav_step<false, true>(sc.tm, t, &s_stack[threadIdx.x], glane, tc)) {
+        if (trav_step<false, true>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
             have_ray = false;
             float tmax = t.tmax;
             uint32_t tri = t.hit;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const flo
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     TraceCount tc = {0, 0, 0, 0};
     WaveFeed feed = wave_feed(n, feed_counters);
-    Trav t;
+    Trav t = {};
     bool have = false;
     uint32_t cur = 0;
     for (;;) {
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const flo
             have = true;
         }
         if (!__any(have)) break;
-        if (have && trav_step<COUNT>(tm, t, &s_stack[threadIdx.x], glane, tc)) {
+        if (trav_step<COUNT>(tm, t, have, &s_stack[threadIdx.x], glane, tc)) {
             have = false;
             float* h = hits + 6 * (size_t)cur;
             h[0] = trav_finish(tm, t);
@@ -1019,6 +1019,7 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     s->ks.tm.spill = nullptr;  // allocated with the queues (ensure_spill)
     s->ks.tm.spill_stride = 0;
     s->ks.tm.stack_cap = WAPT_LDS_STACK;
+    s->ks.tm.tri_quorum = (int32_t)env_u32("WAPT_TRI_QUORUM", 1);
     s->ks.mats = (const DMaterial*)s->d_mats;
     s->ks.lights = (const DLight*)s->d_lights;
     s->ks.n_lights = desc->n_lights;
