@@ -142,6 +142,10 @@ def main():
         st = step(profile=2)
         nodes_per_ray = st.trace_node_visits / max(st.n_trace_rays, 1)
         tris_per_ray = st.trace_tri_tests / max(st.n_trace_rays, 1)
+        util = {"wave_steps_per_ray_x64": 64.0 * st.trace_wave_steps / max(st.n_trace_rays, 1),
+                "node_phase_lane_util": st.trace_node_visits / max(64.0 * st.trace_node_steps, 1),
+                "tri_phase_lane_util": st.trace_tri_tests / max(64.0 * st.trace_tri_trips, 1),
+                "node_phases": int(st.trace_node_steps), "tri_trips": int(st.trace_tri_trips)}
         bytes_per_ray = 32 + 8 + info.node_size * nodes_per_ray + info.tri_size * tris_per_ray
         rays_per_launch = n_rays / max(n_launch, 1)
         avg_ms = ms_trace / max(n_launch, 1)
@@ -161,7 +165,7 @@ def main():
                            "tri_tests_per_ray": tris_per_ray, "rays_per_launch": rays_per_launch,
                            "avg_launch_ms": avg_ms, "launches_per_step": int(n_launch),
                            "grays_per_s_in_kernel": rays_per_launch / (avg_ms * 1e-3) / 1e9,
-                           "kernel_ms_per_step": fam, "shadow_rays_per_step": int(shadow_rays)}
+                           "kernel_ms_per_step": fam, "lane_utilisation": util, "shadow_rays_per_step": int(shadow_rays)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

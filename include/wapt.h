@@ -128,6 +128,9 @@ typedef struct wapt_stats {
     uint64_t n_shadow_launches, n_shadow_rays;
     /* filled when profile bit 1 is set: totals over the closest-hit kernel's rays */
     uint64_t trace_node_visits, trace_tri_tests;
+    /* same build, per wave: loop iterations, iterations whose node phase ran, trips of the triangle
+     * loop (lane utilisation of a phase = visits or tests / (64 x its count)) */
+    uint64_t trace_wave_steps, trace_node_steps, trace_tri_trips;
 } wapt_stats;
 
 typedef struct wapt_ray {
@@ -154,6 +157,7 @@ typedef struct wapt_bvh_info {
 
 typedef struct wapt_trace_counters {
     uint64_t rays, node_visits, tri_tests, stack_spills;
+    uint64_t wave_steps, node_steps, tri_trips; /* per wave, as in wapt_stats */
 } wapt_trace_counters;
 
 typedef struct wapt_scene wapt_scene;        /* scene resident on one GPU */

@@ -43,7 +43,8 @@ class Stats(C.Structure):
                 ("ms_volume", C.c_double), ("ms_shadow", C.c_double), ("ms_probe", C.c_double),
                 ("n_trace_launches", C.c_uint64), ("n_trace_rays", C.c_uint64),
                 ("n_shadow_launches", C.c_uint64), ("n_shadow_rays", C.c_uint64),
-                ("trace_node_visits", C.c_uint64), ("trace_tri_tests", C.c_uint64)]
+                ("trace_node_visits", C.c_uint64), ("trace_tri_tests", C.c_uint64),
+                ("trace_wave_steps", C.c_uint64), ("trace_node_steps", C.c_uint64), ("trace_tri_trips", C.c_uint64)]
 
 
 class Ray(C.Structure):
@@ -61,4 +62,5 @@ class BvhInfo(C.Structure):
 
 class TraceCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("stack_spills", C.c_uint64)]
+                ("stack_spills", C.c_uint64),
+                ("wave_steps", C.c_uint64), ("node_steps", C.c_uint64), ("tri_trips", C.c_uint64)]

@@ -20,6 +20,13 @@
 #define WAPT_BLOCK 256
 #define WAPT_LDS_STACK 8
 #define WAPT_STACK_CAP 32
+// waves per SIMD the register allocator must leave room for (second argument of __launch_bounds__)
+#ifndef WAPT_TRACE_WAVES
+#define WAPT_TRACE_WAVES 6
+#endif
+#ifndef WAPT_SHADOW_WAVES
+#define WAPT_SHADOW_WAVES 5
+#endif
 
 struct TraceMem {
     const uint4* __restrict__ nodes;   // 5 x uint4 per node
@@ -32,6 +39,9 @@ struct TraceMem {
 
 struct TraceCount {
     uint32_t nodes, tris, spills, overflow;
+    // wave-level tallies of the counting build (equal in all lanes of a wave): loop iterations,
+    // iterations whose node phase ran, trips of the triangle loop
+    uint32_t wsteps, nsteps, ttrips;
 };
 
 __device__ __forceinline__ float ubyte_f(uint32_t w, int j) { return (float)((w >> (8 * j)) & 0xffu); }
@@ -103,9 +113,15 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
     const float tiny = 1e-18f;
     t.o = o;
     t.d = d;
+#ifdef WAPT_FAST_RCP
+    t.idx = __builtin_amdgcn_rcpf(fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+    t.idy = __builtin_amdgcn_rcpf(fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+    t.idz = __builtin_amdgcn_rcpf(fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+#else
     t.idx = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
     t.idy = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
     t.idz = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+#endif
     t.tmin = tmin;
     t.tmax = tmax;
     t.octinv = (d.x < 0.f ? 0u : 4u) | (d.y < 0.f ? 0u : 2u) | (d.z < 0.f ? 0u : 1u);
@@ -133,6 +149,10 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
                                           TraceCount& cnt) {
     const int tri_quorum = m.tri_quorum;
     bool descend = have && t.T.y == 0u;
+    if (COUNT) {
+        cnt.wsteps++;
+        cnt.nsteps += __any(descend) ? 1u : 0u;
+    }
     if (descend && (t.G.y & 0xff000000u) == 0u) {
         // current group exhausted: pop, or finish
         if (t.sp == 0) return true;
@@ -191,6 +211,11 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
     if (waiting >= tri_quorum || (waiting > 0 && !__any(can_descend))) {
         // (lanes without a ray, whose state is stale, stay out: `bits` is zero for them)
         uint32_t bits = pending ? t.T.y : 0u;
+        if (COUNT) {
+            uint32_t trips = (uint32_t)__popc(bits);
+            for (int o = 32; o > 0; o >>= 1) trips = max(trips, (uint32_t)__shfl_xor((int)trips, o));
+            cnt.ttrips += trips;
+        }
         while (bits) {
             uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
             bits &= bits - 1u;
@@ -319,5 +344,3 @@ __device__ __forceinline__ WaveFeed wave_feed(uint32_t n, uint32_t* counters) {
     f.dry = n == 0;
     return f;
 }
-
-static inline uint32_t feed_blocks(uint64_t n) { return (uint32_t)((n + 1023) / 1024); }

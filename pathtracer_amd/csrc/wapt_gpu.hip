@@ -233,10 +233,10 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_raygen(KScene sc, KQueues q, KP
 // COUNT adds node-visit and triangle-test tallies (rays[1], rays[2]) for the bytes-per-ray figure of
 // the roofline.
 template <bool COUNT>
-__global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int depth, uint32_t start, uint32_t n) {
+__global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene sc, KQueues q, int depth, uint32_t start, uint32_t n) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
-    TraceCount tc = {0, 0, 0, 0};
+    TraceCount tc = {};
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED);
     Trav t = {};
     bool have = false;
@@ -261,6 +261,9 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_trace(KScene sc, KQueues q, int 
         if (lane_id() == 0) {
             atomicAdd(&q.rays[1], (unsigned long long)a);
             atomicAdd(&q.rays[2], (unsigned long long)b);
+            atomicAdd(&q.rays[4], (unsigned long long)tc.wsteps);
+            atomicAdd(&q.rays[5], (unsigned long long)tc.nsteps);
+            atomicAdd(&q.rays[6], (unsigned long long)tc.ttrips);
         }
     }
     if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
@@ -575,37 +578,37 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KP
 
 // visibility() (cpp:693-790): walk from A to B through every surface in between.  Lanes stream
 // tasks like k_trace; a walk that has to continue past a transparent surface keeps its lane.
-__global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
+__global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = q.cnt[CNT_S];
-    TraceCount tc = {0, 0, 0, 0};
+    TraceCount tc = {};
     uint32_t rays = 0;
     const int global_m = sc.n_objects;
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED + 32 * WAPT_FEED_STRIDE);
     Trav t = {};
     bool have_task = false, have_ray = false;
-    // walk state (names as in the reference)
-    V3 B = v3(0, 0, 0), ABn = v3(0, 0, 1), V = v3(1, 1, 1), P0 = v3(0, 0, 0), W = v3(0, 0, 0);
+    // walk state (names as in the reference).  The segment start P0 and the direction ABn live in t.o / t.d;
+    // B, the weight and the pixel stay in the queue and are read again by the few lanes that need them
+    // (registers decide how many waves fit a SIMD here).
+    V3 V = v3(1, 1, 1);
     float ABl = 0.f, d = 0.f;
     int cur = global_m, it = 0;
-    uint32_t pixel = 0;
+    uint32_t task = 0;
     for (;;) {
         uint32_t idx = feed.take(!have_task);
         if (idx != 0xffffffffu) {
-            float4 a = q.SA[idx], b = q.SB[idx], w4 = q.SC[idx];
+            float4 a = q.SA[idx], b = q.SB[idx];
             V3 A = v3(a.x, a.y, a.z);
-            B = v3(b.x, b.y, b.z);
-            pixel = f2u(a.w);
-            W = v3(w4.x, w4.y, w4.z);
-            V3 AB = B - A;
+            V3 AB = v3(b.x, b.y, b.z) - A;
             ABl = mag(AB);
-            ABn = (1.0f / ABl) * AB;
+            t.o = A;
+            t.d = (1.0f / ABl) * AB;
             V = v3(1.f, 1.f, 1.f);
-            P0 = A;
             d = 0.f;
             cur = global_m;
             it = 0;
+            task = idx;
             have_task = ABl > 0.f;
         }
         if (have_task && !have_ray) {
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
             // the fp32 error of search distances (about 2e-5 relative); the walk's own tests below use the
             // refined distance and the reference's thresholds.
             float rest = ABl - d, margin = 0.002f + 1e-4f * ABl;
-            trav_begin(t, P0, ABn, WAPT_TRACE_BIAS, rest + margin);
+            trav_begin(t, t.o, t.d, WAPT_TRACE_BIAS, rest + margin);
             t.tblock = rest - margin;
             have_ray = true;
             rays++;
@@ -623,6 +626,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
         if (!__any(have_task)) break;
         if (trav_step<false, true>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
             have_ray = false;
+            const V3 P0 = t.o, ABn = t.d;
             float tmax = t.tmax;
             uint32_t tri = t.hit;
             if (tri != 0xffffffffu) {
@@ -630,11 +634,12 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
                 // distance with |AB| +- 0.001, so a hit clearly beyond B needs no better value (B itself is
                 // used); one before or near B gets the fp64 distance (it may seed the next segment)
                 float dd32 = d + tmax;
-                if (!(dd32 > ABl + (0.002f + 5e-5f * ABl))) tmax = refine_distance(sc.tm.tris, tri, t.o, t.d, t.tmin, tmax);
+                if (!(dd32 > ABl + (0.002f + 5e-5f * ABl))) tmax = refine_distance(sc.tm.tris, tri, P0, ABn, WAPT_TRACE_BIAS, tmax);
             }
             V3 P1;
             bool entering = false, opaque = false, blocked = false, lit = false;
             int obj = -1;
+            float seg;   // |P1 - P0|
             V3 hp = point_at(P0, tmax, ABn);
             if (tri != 0xffffffffu) d += mag(hp - P0);
             else d = 2.0f * ABl;
@@ -643,6 +648,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
                 V3 N = normalized(tri_normal(sc.tm.tris, tri, &obj, &prim));
                 const DMaterial& m = sc.mats[obj];
                 P1 = hp;
+                seg = mag(P1 - P0);
                 entering = dot(ABn, N) < 0.0f;
                 opaque = (m.flags & WAPT_MAT_OPAQUE) != 0u;
                 if (entering) {
@@ -653,22 +659,32 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_shadow(KScene sc, KQueues q) {
                     cur = obj;
                 }
             } else {
-                P1 = B;
+                // the segment ends at B; on the first segment P0 is A and |B - A| is ABl itself
+                P1 = P0;
+                seg = ABl;
+                if (it > 0) {
+                    float4 b = q.SB[task];
+                    seg = mag(v3(b.x, b.y, b.z) - P0);
+                }
                 d = ABl;
             }
             if (!blocked) {
-                V = V * attenuation(sc.mats[cur], mag(P1 - P0));
+                V = V * attenuation(sc.mats[cur], seg);
                 if (d >= ABl - WAPT_TRACE_BIAS) lit = true;
                 else if (opaque) blocked = true;
                 else if (V.x < WAPT_LOW_VIS && V.y < WAPT_LOW_VIS && V.z < WAPT_LOW_VIS) blocked = true;
             }
             if (!blocked && !lit && ++it >= 4096) blocked = true;
             if (lit || blocked) {
-                DBG(pixel, "shadow B=(%.5f %.5f %.5f) lit=%d V=%g w=%g d=%.6f ABl=%.6f\n", B.x, B.y, B.z, (int)lit, V.x, W.x, d, ABl);
-                if (lit) add_rgb(q.sum, pixel, W * V);
+                if (lit) {
+                    float4 w4 = q.SC[task];
+                    uint32_t pixel = f2u(q.SA[task].w);
+                    DBG(pixel, "shadow task=%u lit V=%g w=%g d=%.6f ABl=%.6f\n", task, V.x, w4.x, d, ABl);
+                    add_rgb(q.sum, pixel, v3(w4.x, w4.y, w4.z) * V);
+                }
                 have_task = false;
             } else {
-                P0 = P1;
+                t.o = P1;
                 cur = entering ? obj : global_m;
             }
         }
@@ -683,7 +699,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = q.cnt[CNT_P];
-    TraceCount tc = {0, 0, 0, 0};
+    TraceCount tc = {};
     uint32_t rays = 0;
     for (uint32_t i = glane; i < n; i += gridDim.x * blockDim.x) {
         float4 a = q.PA[i], b = q.PB[i], w4 = q.PC[i];
@@ -738,7 +754,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const flo
                                                           unsigned long long* counters, uint32_t* feed_counters) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
-    TraceCount tc = {0, 0, 0, 0};
+    TraceCount tc = {};
     WaveFeed feed = wave_feed(n, feed_counters);
     Trav t = {};
     bool have = false;
@@ -777,6 +793,9 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const flo
             atomicAdd(&counters[0], (unsigned long long)a);
             atomicAdd(&counters[1], (unsigned long long)b);
             atomicAdd(&counters[2], (unsigned long long)c);
+            atomicAdd(&counters[4], (unsigned long long)tc.wsteps);
+            atomicAdd(&counters[5], (unsigned long long)tc.nsteps);
+            atomicAdd(&counters[6], (unsigned long long)tc.ttrips);
         }
     }
     uint32_t ov = wave_sum(tc.overflow);
@@ -809,7 +828,7 @@ struct wapt_scene {
     void* d_queue_block = nullptr;
     size_t queue_bytes = 0;
     int queue_depths = 0;
-    uint32_t grid = 0;
+    uint32_t grid = 0, sgrid = 0;
     uint32_t capR = 0, capS = 0, capP = 0;
     bool has_scatter = false, has_inside = false;
     float max_segment = 0.f;
@@ -1007,10 +1026,11 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     HIPCHK_S(hipGetDeviceProperties(&prop, device));
     uint32_t cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
     s->grid = cus * env_u32("WAPT_BLOCKS_PER_CU", 6);
+    s->sgrid = std::max(1u, cus * env_u32("WAPT_SBLOCKS_PER_CU", 2));  // 1024-thread blocks of the shading kernels
     HIPCHK_S(hipMalloc((void**)&s->d_cnt, CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK_S(hipMemset(s->d_cnt, 0, CNT_TOTAL * sizeof(uint32_t)));
-    HIPCHK_S(hipMalloc((void**)&s->d_rays, 4 * sizeof(unsigned long long)));
-    HIPCHK_S(hipMemset(s->d_rays, 0, 4 * sizeof(unsigned long long)));
+    HIPCHK_S(hipMalloc((void**)&s->d_rays, 8 * sizeof(unsigned long long)));
+    HIPCHK_S(hipMemset(s->d_rays, 0, 8 * sizeof(unsigned long long)));
     HIPCHK_S(hipHostMalloc((void**)&s->h_cnt, CNT_TOTAL * sizeof(uint32_t) + 64));
 
     memset(&s->ks, 0, sizeof(s->ks));
@@ -1067,10 +1087,10 @@ extern "C" int wapt_scene_bvh_info(const wapt_scene* s, wapt_bvh_info* o) {
 
 namespace {
 
-// Spill area of the traversal stacks: (tree depth - LDS entries) slots for every lane of the largest launch.
-int ensure_spill(wapt_scene* s, uint64_t max_items) {
-    uint32_t blocks = std::max(feed_blocks(max_items), s->grid);
-    uint32_t lanes = blocks * WAPT_BLOCK;
+// Spill area of the traversal stacks: (tree depth - LDS entries) slots for every lane of a traversal launch
+// (all of them use the same fixed grid).
+int ensure_spill(wapt_scene* s) {
+    uint32_t lanes = s->grid * WAPT_BLOCK;
     if (s->d_spill && s->ks.tm.spill_stride >= lanes) return WAPT_OK;
     if (s->d_spill) HIPCHK(hipFree(s->d_spill));
     s->d_spill = nullptr;
@@ -1083,19 +1103,42 @@ int ensure_spill(wapt_scene* s, uint64_t max_items) {
     return WAPT_OK;
 }
 
-// (Re)allocates the work queues for a trace depth.
-int ensure_queues(wapt_scene* s, int td) {
+// (Re)allocates the work queues for a trace depth and a call that issues `paths` top-level tasks.
+// Capacities: large launches matter more than anything else for the traversal kernels (a launch ends
+// with a tail in which most lanes have run out of work: at 2^22 tasks per launch the lanes of the
+// closest-hit kernel were busy 55 % of the time, at 2^26 90 %), and HBM is plentiful, so the default
+// is 2^26 tasks per depth (3 GiB per depth) and 2^27 shadow / probe tasks for scenes with media, cut
+// down to what the call can use and to a quarter of the free device memory.
+int ensure_queues(wapt_scene* s, int td, uint64_t paths) {
     int depths = td + 1;
-    if (s->d_queue_block && s->queue_depths >= depths) return WAPT_OK;
-    if (s->d_queue_block) {
-        HIPCHK(hipFree(s->d_queue_block));
-        s->d_queue_block = nullptr;
-    }
-    uint32_t capR = env_u32("WAPT_RAD_CAP", 1u << 22);
+    uint32_t capR = env_u32("WAPT_RAD_CAP", s->has_scatter ? (1u << 24) : (1u << 26));
+    capR = (uint32_t)std::min<uint64_t>(capR, (paths + 4095) & ~(uint64_t)4095);
     capR = std::max(capR, 64u * 64u);
     capR &= ~63u;
-    uint32_t capS = env_u32("WAPT_SHADOW_CAP", s->has_scatter ? (1u << 24) : capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
-    uint32_t capP = env_u32("WAPT_PROBE_CAP", s->has_scatter ? (1u << 24) : 64u);
+    uint32_t capS = env_u32("WAPT_SHADOW_CAP", s->has_scatter ? (1u << 27) : capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
+    uint32_t capP = env_u32("WAPT_PROBE_CAP", s->has_scatter ? (1u << 27) : 64u);
+    auto footprint = [&](uint64_t r, uint64_t sh, uint64_t pr) {
+        return (uint64_t)depths * r * 48 + sh * 48 + pr * 48 + r * 24;
+    };
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = (uint64_t)(free_b + s->queue_bytes) / 4;
+    while (footprint(capR, capS, capP) > budget && (capR > (1u << 16) || capS > (1u << 20))) {
+        if (capR > (1u << 16)) capR >>= 1;
+        if (capS > (1u << 20)) capS >>= 1;
+        if (capP > (1u << 20)) capP >>= 1;
+    }
+    if (s->d_queue_block && s->queue_depths >= depths && s->capR >= capR && s->capS >= capS && s->capP >= capP) return WAPT_OK;
+    if (s->d_queue_block) {
+        // keep what an earlier, larger call allocated for the dimensions that do not grow
+        capR = std::max(capR, s->capR);
+        capS = std::max(capS, s->capS);
+        capP = std::max(capP, s->capP);
+        depths = std::max(depths, s->queue_depths);
+        HIPCHK(hipFree(s->d_queue_block));
+        s->d_queue_block = nullptr;
+        s->queue_bytes = 0;
+    }
     size_t bytes = 0;
     auto take = [&](size_t b) {
         size_t off = bytes;
@@ -1134,7 +1177,7 @@ int ensure_queues(wapt_scene* s, int td) {
     s->capP = capP;
     s->queue_bytes = bytes;
     s->queue_depths = depths;
-    return ensure_spill(s, std::max<uint64_t>(capR, std::max(capS, capP)));
+    return ensure_spill(s);
 }
 
 struct Timer {
@@ -1176,7 +1219,8 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     if (prm->sample_begin < 0 || prm->sample_count < 0) return wapt_fail(WAPT_E_INVALID, "bad sample range");
     if (!(prm->mr >= 0.f) || !(prm->me >= 0.f)) return wapt_fail(WAPT_E_INVALID, "mr and me must be >= 0");
     HIPCHK(hipSetDevice(s->device));
-    int rc = ensure_queues(s, prm->max_depth);
+    const uint64_t n_paths = (uint64_t)((s->ks.cam.resI + 7) / 8) * (uint64_t)((s->ks.cam.resJ + 7) / 8) * 64u * (uint64_t)prm->sample_count;
+    int rc = ensure_queues(s, prm->max_depth, n_paths);
     if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
 
@@ -1200,7 +1244,7 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     const KScene& ks = s->ks;
     hipStream_t st = s->stream;
     const dim3 grid(s->grid), block(WAPT_BLOCK);
-    const dim3 sgrid(std::max(1u, s->grid * WAPT_BLOCK / WAPT_SBLOCK)), sblock(WAPT_SBLOCK);
+    const dim3 sgrid(s->sgrid), sblock(WAPT_SBLOCK);
 
     // worst-case fan-out of one task of depth d (sizes the chunk taken from R[d])
     const int L = s->n_lights;
@@ -1228,7 +1272,7 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     const unsigned long long total = (unsigned long long)kp.slots_per_sample * (unsigned long long)prm->sample_count;
     unsigned long long issued = 0;
     uint64_t rays_trace = 0, n_trace_launches = 0, n_shadow_launches = 0;
-    HIPCHK(hipMemsetAsync(s->d_rays, 0, 4 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(s->d_rays, 0, 8 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, CNT_OVERFLOW, 0u);
 
     for (;;) {
@@ -1283,7 +1327,7 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
             have[d + 1] = std::min(s->h_cnt[CNT_R0 + d + 1], s->capR);
         }
     }
-    unsigned long long h_rays[4] = {0, 0, 0, 0};
+    unsigned long long h_rays[8] = {0};
     HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(h_rays, s->d_rays, sizeof(h_rays), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1301,6 +1345,9 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
         stats->n_shadow_rays = h_rays[0];
         stats->trace_node_visits = h_rays[1];
         stats->trace_tri_tests = h_rays[2];
+        stats->trace_wave_steps = h_rays[4];
+        stats->trace_node_steps = h_rays[5];
+        stats->trace_tri_trips = h_rays[6];
         if (tm.on) {
             double ms[FAM_N] = {0};
             for (auto& r : tm.recs) {
@@ -1352,7 +1399,7 @@ extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint
                                      wapt_trace_counters* counters, float* ms) {
     if (!s || (n && (!d_rays || !d_hits))) return wapt_fail(WAPT_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipMemsetAsync(s->d_rays, 0, 4 * sizeof(unsigned long long), s->stream));
+    HIPCHK(hipMemsetAsync(s->d_rays, 0, 8 * sizeof(unsigned long long), s->stream));
     hipEvent_t a = nullptr, b = nullptr;
     if (ms) {
         HIPCHK(hipEventCreate(&a));
@@ -1360,9 +1407,8 @@ extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint
         HIPCHK(hipEventRecord(a, s->stream));
     }
     {
-        // batches of at most 2^22 rays keep the stack spill area small
-        const uint32_t batch = 1u << 22;
-        int rc = ensure_spill(s, batch);
+        const uint32_t batch = 1u << 30;  // one launch unless the batch is enormous
+        int rc = ensure_spill(s);
         if (rc) return rc;
         for (uint64_t off = 0; off < n; off += batch) {
             uint32_t m = (uint32_t)std::min<uint64_t>(batch, n - off);
@@ -1376,7 +1422,7 @@ extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint
         }
     }
     if (ms) HIPCHK(hipEventRecord(b, s->stream));
-    unsigned long long h[4] = {0, 0, 0, 0};
+    unsigned long long h[8] = {0};
     HIPCHK(hipMemcpyAsync(h, s->d_rays, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipGetLastError());
@@ -1390,6 +1436,9 @@ extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint
         counters->node_visits = h[0];
         counters->tri_tests = h[1];
         counters->stack_spills = h[2];
+        counters->wave_steps = h[4];
+        counters->node_steps = h[5];
+        counters->tri_trips = h[6];
     }
     if (h[3]) return wapt_fail(WAPT_E_LIMIT, "traversal stack overflow");
     return WAPT_OK;
