@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--scene", type=str, default="dragonChrome", choices=["dragonChrome", "dragonGlass", "dragonMilk", "cornell", "fog"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=4)
+    ap.add_argument("--cpu-spp", type=int, default=32)
     args = ap.parse_args()
 
     import numpy as np
@@ -145,7 +145,12 @@ def main():
         util = {"wave_steps_per_ray_x64": 64.0 * st.trace_wave_steps / max(st.n_trace_rays, 1),
                 "node_phase_lane_util": st.trace_node_visits / max(64.0 * st.trace_node_steps, 1),
                 "tri_phase_lane_util": st.trace_tri_tests / max(64.0 * st.trace_tri_trips, 1),
-                "node_phases": int(st.trace_node_steps), "tri_trips": int(st.trace_tri_trips)}
+                "node_phases": int(st.trace_node_steps), "tri_trips": int(st.trace_tri_trips),
+                "shadow": {"node_visits_per_ray": st.shadow_node_visits / max(st.n_shadow_rays, 1),
+                           "tri_tests_per_ray": st.shadow_tri_tests / max(st.n_shadow_rays, 1),
+                           "wave_steps_per_ray_x64": 64.0 * st.shadow_wave_steps / max(st.n_shadow_rays, 1),
+                           "node_phase_lane_util": st.shadow_node_visits / max(64.0 * st.shadow_node_steps, 1),
+                           "tri_phase_lane_util": st.shadow_tri_tests / max(64.0 * st.shadow_tri_trips, 1)}}
         bytes_per_ray = 32 + 8 + info.node_size * nodes_per_ray + info.tri_size * tris_per_ray
         rays_per_launch = n_rays / max(n_launch, 1)
         avg_ms = ms_trace / max(n_launch, 1)

@@ -131,6 +131,8 @@ typedef struct wapt_stats {
     /* same build, per wave: loop iterations, iterations whose node phase ran, trips of the triangle
      * loop (lane utilisation of a phase = visits or tests / (64 x its count)) */
     uint64_t trace_wave_steps, trace_node_steps, trace_tri_trips;
+    /* the same five tallies for the rays of the shadow walks */
+    uint64_t shadow_node_visits, shadow_tri_tests, shadow_wave_steps, shadow_node_steps, shadow_tri_trips;
 } wapt_stats;
 
 typedef struct wapt_ray {

@@ -44,7 +44,9 @@ class Stats(C.Structure):
                 ("n_trace_launches", C.c_uint64), ("n_trace_rays", C.c_uint64),
                 ("n_shadow_launches", C.c_uint64), ("n_shadow_rays", C.c_uint64),
                 ("trace_node_visits", C.c_uint64), ("trace_tri_tests", C.c_uint64),
-                ("trace_wave_steps", C.c_uint64), ("trace_node_steps", C.c_uint64), ("trace_tri_trips", C.c_uint64)]
+                ("trace_wave_steps", C.c_uint64), ("trace_node_steps", C.c_uint64), ("trace_tri_trips", C.c_uint64),
+                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64), ("shadow_wave_steps", C.c_uint64),
+                ("shadow_node_steps", C.c_uint64), ("shadow_tri_trips", C.c_uint64)]
 
 
 class Ray(C.Structure):

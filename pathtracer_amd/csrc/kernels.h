@@ -28,9 +28,9 @@ enum {
     CNT_S,        // shadow-walk tasks
     CNT_P,        // probe tasks
     CNT_OVERFLOW, // traversal pushes dropped + queue pushes dropped (must stay 0)
-    CNT_FEED = 128, // 2 x 32 work-feed counters of k_trace and k_shadow, 64 words apart (zeroed by k_reset)
+    CNT_FEED = 128, // 3 x 32 work-feed counters of k_trace, k_shadow and k_probe, 64 words apart (zeroed by k_reset)
     CNT_R0 = 8,   // CNT_R0 + d: tasks in R[d]
-    CNT_TOTAL = 128 + 2 * 32 * 64
+    CNT_TOTAL = 128 + 3 * 32 * 64
 };
 
 enum { RAY_CAMERA = 0, RAY_DIFFUSE = 1, RAY_SPECULAR = 2 };  // unidirectionalPathTracer.h:9-11
@@ -65,4 +65,7 @@ struct KParams {
     uint32_t slots_per_sample;  // tilesX*tilesY*64
     uint32_t tilesX;
     int32_t dense_raygen;       // W and H are multiples of 8: every slot is a pixel sample
+    uint32_t sample_count;      // samples of this call
+    int32_t write_hits;         // the scene has media: keep refined hits and the list of marched segments for k_volume
+    int32_t pixel_major;        // task order: all samples of a pixel next to each other (else sample by sample)
 };

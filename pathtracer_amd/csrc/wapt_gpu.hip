@@ -158,6 +158,16 @@ __device__ __forceinline__ void load_task(const KQueues& q, int depth, uint32_t 
     c.stream = wapt_stream(c.key, c.pixel);
 }
 
+__device__ __forceinline__ void set_hit(const KScene& sc, uint2 h, HitCtx& c) {
+    c.t = u2f(h.x);
+    c.tri = h.y;
+    if (c.tri == 0xffffffffu) return;
+    int prim;
+    c.N = normalized(tri_normal(sc.tm.tris, c.tri, &c.obj, &prim));
+    c.P = point_at(c.o, c.t, c.dir);  // content.cpp:98-100
+    c.entering = dot(c.N, -c.dir) > 0.0f;
+}
+
 __device__ __forceinline__ void load_hit(const KScene& sc, const KQueues& q, uint32_t i, HitCtx& c) {
     uint2 h = q.hits[i];
     c.t = u2f(h.x);
@@ -195,7 +205,7 @@ __device__ __forceinline__ V3 surface_weight(const KScene& sc, const HitCtx& c) 
 __global__ void k_reset(uint32_t* cnt, int r_slot, uint32_t r_value) {
     uint32_t t = threadIdx.x;
     if (t <= CNT_P) cnt[t] = 0u;
-    cnt[CNT_FEED + t * WAPT_FEED_STRIDE] = 0u;  // 64 threads, 64 feed counters
+    cnt[CNT_FEED + t * WAPT_FEED_STRIDE] = 0u;  // 96 threads, 96 feed counters (three traversal kernels per step)
     if (r_slot >= 0 && t == 0) cnt[r_slot] = r_value;
 }
 
@@ -204,8 +214,14 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_raygen(KScene sc, KQueues q, KP
     GRID_LOOP(i, n) {
         bool valid = i < n;
         unsigned long long path = p0 + i;
-        uint32_t s_local = (uint32_t)(path / p.slots_per_sample);
-        uint32_t r = (uint32_t)(path % p.slots_per_sample);
+        uint32_t s_local, r;
+        if (p.pixel_major) {
+            r = (uint32_t)(path / p.sample_count);
+            s_local = (uint32_t)(path % p.sample_count);
+        } else {
+            s_local = (uint32_t)(path / p.slots_per_sample);
+            r = (uint32_t)(path % p.slots_per_sample);
+        }
         uint32_t tile = r >> 6, within = r & 63u;
         int px = (int)((tile % p.tilesX) * 8u + (within & 7u));
         int py = (int)((tile / p.tilesX) * 8u + (within >> 3));
@@ -269,24 +285,37 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene s
     if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
 }
 
-// Head of radiance(): miss handling, roulette, emission, classification (cpp:218-263, 290)
-__global__ __launch_bounds__(WAPT_SBLOCK) void k_head(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
+// radiance() from the closest hit on (cpp:218-290) for every task of the step, in one pass over the
+// queue: miss handling, roulette, emission, then the surface event of the hit material -
+// Lambert: directReflection (cpp:345-381) + indirectReflection (cpp:383-405); mirror: the specular
+// branch of reflection() (cpp:329-336); dielectric: the reflect-or-transmit choice (cpp:266-280),
+// transmission() (cpp:296-311) and the dielectric branch of reflection() (cpp:329-341).
+// The kernel moves 48 B of task, 8 B of hit and 48 B of triangle in and 48 B per child or shadow task
+// out and is bound by that traffic, not by arithmetic: the materials share one kernel (lanes of a wave
+// may run different branches) so that nothing is read twice.
+__global__ __launch_bounds__(WAPT_SBLOCK) void k_surface(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
+    enum { NONE, LAMBERT, MIRROR, DIELECTRIC };
     GRID_LOOP(i, n) {
-        bool valid = i < n;
-        bool toL = false, toS = false, toD = false, toV = false;
+        const bool valid = i < n;
+        HitCtx c = {};
+        int kind = NONE;
+        bool toV = false;
+        V3 w = v3(0, 0, 0), N1f = v3(0, 0, 1), kd = v3(0, 0, 0);
+        // the one child of a mirror or dielectric event
+        bool cemit = false;
+        V3 cdir = v3(0, 0, 1), cb = v3(0, 0, 0);
+        uint32_t cinfo = 0, ckey = 0;
         if (valid) {
-            HitCtx c = {};
             load_task(q, depth, start, i, c);
-            {
+            uint2 h = q.hits[i];
+            if (h.y != 0xffffffffu) {
                 // the closest-hit kernel leaves the fp32 distance of its search; the fp64 re-evaluation runs
-                // here, where every lane has a hit to refine, and is written back for the shading kernels
-                uint2 h = q.hits[i];
-                if (h.y != 0xffffffffu) {
-                    float tr = refine_distance(sc.tm.tris, h.y, c.o, c.dir, WAPT_TRACE_BIAS, u2f(h.x));
-                    q.hits[i] = make_uint2(f2u(tr), h.y);
-                }
+                // here, where every lane has a hit to refine (the march kernel reads it back from the queue)
+                float tr = refine_distance(sc.tm.tris, h.y, c.o, c.dir, WAPT_TRACE_BIAS, u2f(h.x));
+                h.x = f2u(tr);
+                if (p.write_hits) q.hits[i] = h;
             }
-            load_hit(sc, q, i, c);
+            set_hit(sc, h, c);
             DBG(c.pixel, "head d=%d key=%08x o=(%.6f %.6f %.6f) dir=(%.7f %.7f %.7f) t=%.6f tri=%u P=(%.6f %.6f %.6f) obj=%d beta=%g\n", depth, c.key, c.o.x, c.o.y, c.o.z, c.dir.x, c.dir.y, c.dir.z, c.t, c.tri, c.P.x, c.P.y, c.P.z, c.obj, c.beta.x);
             if (c.tri == 0xffffffffu) {
                 // cpp:221-230: the segment to the world sphere is lit through the GLOBAL medium
@@ -294,54 +323,64 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_head(KScene sc, KQueues q, KPar
                 V3 rel = c.o - ld3(sc.wc);
                 toV = g.scatters && (mag(rel) < sc.wr);
             } else {
+                const DMaterial& m = sc.mats[c.obj];
                 float xs = wapt_rand(c.stream, WAPT_DIM_SURF);
                 if (xs < p_surface(depth)) {
-                    const DMaterial& m = sc.mats[c.obj];
-                    if (info_emit(c.info) && c.obj < sc.n_lights) {
-                        V3 w = surface_weight(sc, c);
+                    w = surface_weight(sc, c);
+                    if (info_emit(c.info) && c.obj < sc.n_lights)
                         add_rgb(q.sum, c.pixel, w * ld3(sc.lights[c.obj].Li));  // primitive.cpp:21-29
-                    }
-                    if (m.flags & WAPT_MAT_DIFFUSE) toL = true;
-                    else if (m.flags & WAPT_MAT_SPECULAR) toS = true;
-                    else if (m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) toD = true;
+                    if (m.flags & WAPT_MAT_DIFFUSE) kind = LAMBERT;
+                    else if (m.flags & WAPT_MAT_SPECULAR) kind = MIRROR;
+                    else if (m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) kind = DIELECTRIC;
                 }
                 toV = medium_of(sc, info_medium(c.info)).scatters != 0u;
+                N1f = c.entering ? c.N : -c.N;
+                if (kind == LAMBERT) {
+                    kd = ld3(m.kd);
+                } else if (kind == MIRROR) {
+                    if (info_raytype(c.info) != RAY_DIFFUSE && depth + 1 <= p.td) {
+                        cdir = reflect_dir(-c.dir, N1f);
+                        cb = w * ld3(m.ks);
+                        cinfo = make_info(depth + 1, info_emit(c.info), RAY_SPECULAR, info_medium(c.info));
+                        ckey = wapt_key_child(c.key, WAPT_SLOT_SPEC);
+                        cemit = true;
+                    }
+                } else if (kind == DIELECTRIC) {
+                    V3 D = -c.dir;
+                    float F;
+                    V3 D2 = refract_dir(c.N, D, m.ior, &F);
+                    float pR = (1.0f - WAPT_BLEND) * 0.5f + WAPT_BLEND * F;
+                    bool transmit = wapt_rand(c.stream, WAPT_DIM_DIEL) < (1.0f - pR);
+                    if (depth + 1 <= p.td) {
+                        if (transmit) {
+                            bool kt_nonzero = m.kt[0] != 0.f || m.kt[1] != 0.f || m.kt[2] != 0.f;
+                            if (kt_nonzero && !is_zero(D2)) {
+                                cdir = -D2;
+                                cb = ((1.0f - F) / (1.0f - pR)) * w;
+                                int medium1 = c.entering ? c.obj : -1;
+                                cinfo = make_info(depth + 1, info_emit(c.info), RAY_CAMERA, medium1);
+                                ckey = wapt_key_child(c.key, WAPT_SLOT_TRANS);
+                                cemit = true;
+                            }
+                        } else if (info_raytype(c.info) != RAY_DIFFUSE) {
+                            cdir = reflect_dir(D, N1f);
+                            cb = (F / pR) * (w * ld3(m.ks));
+                            cinfo = make_info(depth + 1, info_emit(c.info), RAY_SPECULAR, info_medium(c.info));
+                            ckey = wapt_key_child(c.key, WAPT_SLOT_SPEC);
+                            cemit = true;
+                        }
+                    }
+                }
             }
         }
-        uint32_t s;
-        s = block_push(&q.cnt[CNT_QL], toL);
-        if (toL) q.QL[s] = i;
-        s = block_push(&q.cnt[CNT_QS], toS);
-        if (toS) q.QS[s] = i;
-        s = block_push(&q.cnt[CNT_QD], toD);
-        if (toD) q.QD[s] = i;
-        s = block_push(&q.cnt[CNT_QV], toV);
-        if (toV) q.QV[s] = i;
-    }
-}
-
-// Lambert surfaces: directReflection (cpp:345-381) + indirectReflection (cpp:383-405)
-__global__ __launch_bounds__(WAPT_SBLOCK) void k_shade_lambert(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
-    uint32_t n = q.cnt[CNT_QL];
-    GRID_LOOP(j, n) {
-        bool valid = j < n;
-        HitCtx c = {};
-        V3 w = v3(0, 0, 0), N1f = v3(0, 0, 1), kd = v3(0, 0, 0);
-        if (valid) {
-            uint32_t i = q.QL[j];
-            load_task(q, depth, start, i, c);
-            load_hit(sc, q, i, c);
-            w = surface_weight(sc, c);
-            N1f = c.entering ? c.N : -c.N;
-            kd = ld3(sc.mats[c.obj].kd);
-        }
-        // next event estimation: one shadow walk per light sample
+        const bool lambert = kind == LAMBERT;
+        // Lambert, next event estimation: one shadow walk per light sample
         float rls = 1.0f / (float)p.lsamples;
         for (int l = 0; l < sc.n_lights; l++) {
             for (int s = 0; s < p.lsamples; s++) {
                 bool emit = false;
                 V3 LP = v3(0, 0, 0), wt = v3(0, 0, 0);
-                if (valid) {
+                if (lambert) {
                     uint32_t dim = WAPT_DIM_NEE + 2u * (uint32_t)(l * p.lsamples + s);
                     float rpdf;
                     const DLight& L = sc.lights[l];
@@ -354,99 +393,36 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_shade_lambert(KScene sc, KQueue
                             emit = true;
                         }
                     }
+                    DBG(c.pixel, "nee d=%d key=%08x emit=%d LP=(%.5f %.5f %.5f) wt=%g\n", depth, c.key, (int)emit, LP.x, LP.y, LP.z, wt.x);
                 }
-                if (valid) DBG(c.pixel, "nee d=%d key=%08x emit=%d LP=(%.5f %.5f %.5f) wt=%g\n", depth, c.key, (int)emit, LP.x, LP.y, LP.z, wt.x);
                 push_shadow(q, emit, c.P, LP, wt, c.pixel);
             }
         }
-        // indirect: hsamples uniform hemisphere directions, no emission at the next hit
-        bool deeper = valid && (depth + 1 <= p.td);
+        // children: hsamples uniform hemisphere directions of a Lambert event (no emission at the next
+        // hit), or the single continuation of a mirror / dielectric event
+        const bool deeper = lambert && (depth + 1 <= p.td);
         float rhs = 1.0f / (float)p.hsamples;
         for (int s = 0; s < p.hsamples; s++) {
-            bool emit = false;
-            V3 Wi = v3(0, 0, 1), b = v3(0, 0, 0);
+            bool emit = cemit && s == 0;
+            V3 dir = cdir, b = cb;
+            uint32_t info = cinfo, key = ckey;
             if (deeper) {
-                Wi = hemisphere_uniform(N1f, wapt_rand(c.stream, WAPT_DIM_HEMI + 2u * s),
-                                        wapt_rand(c.stream, WAPT_DIM_HEMI + 2u * s + 1u));
-                float ndw = dot(Wi, N1f);
+                dir = hemisphere_uniform(N1f, wapt_rand(c.stream, WAPT_DIM_HEMI + 2u * s),
+                                         wapt_rand(c.stream, WAPT_DIM_HEMI + 2u * s + 1u));
+                float ndw = dot(dir, N1f);
                 if (!(ndw < 0.0f)) {
                     b = (rhs * (1.0f / WAPT_PI) * ndw * (2.0f * WAPT_PI)) * (w * kd);
+                    info = make_info(depth + 1, false, RAY_DIFFUSE, info_medium(c.info));
+                    key = wapt_key_child(c.key, WAPT_SLOT_HEMI | (uint32_t)s);
                     emit = true;
                 }
             }
-            push_radiance(q, depth + 1, emit, c.P, Wi, b, c.pixel,
-                          make_info(depth + 1, false, RAY_DIFFUSE, info_medium(c.info)),
-                          wapt_key_child(c.key, WAPT_SLOT_HEMI | (uint32_t)s));
+            push_radiance(q, depth + 1, emit, c.P, dir, b, c.pixel, info, key);
         }
-    }
-}
-
-// Mirror surfaces: the specular branch of reflection() (cpp:329-336)
-__global__ __launch_bounds__(WAPT_SBLOCK) void k_shade_specular(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
-    uint32_t n = q.cnt[CNT_QS];
-    GRID_LOOP(j, n) {
-        bool emit = false;
-        HitCtx c = {};
-        V3 R = v3(0, 0, 1), b = v3(0, 0, 0);
-        if (j < n) {
-            uint32_t i = q.QS[j];
-            load_task(q, depth, start, i, c);
-            load_hit(sc, q, i, c);
-            if (info_raytype(c.info) != RAY_DIFFUSE && depth + 1 <= p.td) {
-                V3 N1f = c.entering ? c.N : -c.N;
-                R = reflect_dir(-c.dir, N1f);
-                b = surface_weight(sc, c) * ld3(sc.mats[c.obj].ks);
-                emit = true;
-            }
+        if (p.write_hits) {
+            uint32_t sv = block_push(&q.cnt[CNT_QV], toV);
+            if (toV) q.QV[sv] = i;
         }
-        push_radiance(q, depth + 1, emit, c.P, R, b, c.pixel,
-                      make_info(depth + 1, info_emit(c.info), RAY_SPECULAR, info_medium(c.info)),
-                      wapt_key_child(c.key, WAPT_SLOT_SPEC));
-    }
-}
-
-// Dielectric surfaces: the reflect-or-transmit choice of radiance() (cpp:266-280),
-// transmission() (cpp:296-311) and the dielectric branch of reflection() (cpp:329-341)
-__global__ __launch_bounds__(WAPT_SBLOCK) void k_shade_dielectric(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
-    uint32_t n = q.cnt[CNT_QD];
-    GRID_LOOP(j, n) {
-        bool emit = false;
-        HitCtx c = {};
-        V3 dir = v3(0, 0, 1), b = v3(0, 0, 0);
-        uint32_t info = 0, key = 0;
-        if (j < n) {
-            uint32_t i = q.QD[j];
-            load_task(q, depth, start, i, c);
-            load_hit(sc, q, i, c);
-            const DMaterial& m = sc.mats[c.obj];
-            V3 D = -c.dir;
-            float F;
-            V3 D2 = refract_dir(c.N, D, m.ior, &F);
-            float pR = (1.0f - WAPT_BLEND) * 0.5f + WAPT_BLEND * F;
-            bool transmit = wapt_rand(c.stream, WAPT_DIM_DIEL) < (1.0f - pR);
-            V3 w = surface_weight(sc, c);
-            if (depth + 1 <= p.td) {
-                if (transmit) {
-                    bool kt_nonzero = m.kt[0] != 0.f || m.kt[1] != 0.f || m.kt[2] != 0.f;
-                    if (kt_nonzero && !is_zero(D2)) {
-                        dir = -D2;
-                        b = ((1.0f - F) / (1.0f - pR)) * w;
-                        int medium1 = c.entering ? c.obj : -1;
-                        info = make_info(depth + 1, info_emit(c.info), RAY_CAMERA, medium1);
-                        key = wapt_key_child(c.key, WAPT_SLOT_TRANS);
-                        emit = true;
-                    }
-                } else if (info_raytype(c.info) != RAY_DIFFUSE) {
-                    V3 N1f = c.entering ? c.N : -c.N;
-                    dir = reflect_dir(D, N1f);
-                    b = (F / pR) * (w * ld3(m.ks));
-                    info = make_info(depth + 1, info_emit(c.info), RAY_SPECULAR, info_medium(c.info));
-                    key = wapt_key_child(c.key, WAPT_SLOT_SPEC);
-                    emit = true;
-                }
-            }
-        }
-        push_radiance(q, depth + 1, emit, c.P, dir, b, c.pixel, info, key);
     }
 }
 
@@ -578,6 +554,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KP
 
 // visibility() (cpp:693-790): walk from A to B through every surface in between.  Lanes stream
 // tasks like k_trace; a walk that has to continue past a transparent surface keeps its lane.
+template <bool COUNT>
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -624,7 +601,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             rays++;
         }
         if (!__any(have_task)) break;
-        if (trav_step<false, true>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
+        if (trav_step<COUNT, true>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
             have_ray = false;
             const V3 P0 = t.o, ABn = t.d;
             float tmax = t.tmax;
@@ -634,7 +611,9 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                 // distance with |AB| +- 0.001, so a hit clearly beyond B needs no better value (B itself is
                 // used); one before or near B gets the fp64 distance (it may seed the next segment)
                 float dd32 = d + tmax;
+#ifndef WAPT_EXP_NO_REFINE
                 if (!(dd32 > ABl + (0.002f + 5e-5f * ABl))) tmax = refine_distance(sc.tm.tris, tri, P0, ABn, WAPT_TRACE_BIAS, tmax);
+#endif
             }
             V3 P1;
             bool entering = false, opaque = false, blocked = false, lit = false;
@@ -680,7 +659,11 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                     float4 w4 = q.SC[task];
                     uint32_t pixel = f2u(q.SA[task].w);
                     DBG(pixel, "shadow task=%u lit V=%g w=%g d=%.6f ABl=%.6f\n", task, V.x, w4.x, d, ABl);
+#ifdef WAPT_EXP_NO_SHADOW_ATOMIC
+                    if (V.x < -1.f) add_rgb(q.sum, pixel, v3(w4.x, w4.y, w4.z) * V);
+#else
                     add_rgb(q.sum, pixel, v3(w4.x, w4.y, w4.z) * V);
+#endif
                 }
                 have_task = false;
             } else {
@@ -691,56 +674,91 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
     }
     rays = wave_sum(rays);
     if (lane_id() == 0 && rays) atomicAdd(q.rays, (unsigned long long)rays);
+    if (COUNT) {
+        uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.tris);
+        if (lane_id() == 0) {
+            atomicAdd(&q.rays[8], (unsigned long long)a);
+            atomicAdd(&q.rays[9], (unsigned long long)b);
+            atomicAdd(&q.rays[10], (unsigned long long)tc.wsteps);
+            atomicAdd(&q.rays[11], (unsigned long long)tc.nsteps);
+            atomicAdd(&q.rays[12], (unsigned long long)tc.ttrips);
+        }
+    }
     if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
 }
 
-// directLightHit (cpp:670-687) and directLightingSingleScatter (cpp:631-665)
+// directLightHit (cpp:670-687) and directLightingSingleScatter (cpp:631-665).  Lanes stream tasks like
+// k_trace; a single-scatter probe that reaches its object's surface keeps its lane for the refracted
+// second ray.
 __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = q.cnt[CNT_P];
     TraceCount tc = {};
     uint32_t rays = 0;
-    for (uint32_t i = glane; i < n; i += gridDim.x * blockDim.x) {
-        float4 a = q.PA[i], b = q.PB[i], w4 = q.PC[i];
-        V3 S = v3(a.x, a.y, a.z), dir = v3(b.x, b.y, b.z), w = v3(w4.x, w4.y, w4.z);
-        uint32_t pixel = f2u(a.w), info = f2u(b.w);
-        int light = (int)(info & 0xffffu);
-        int kind = (int)(info >> 16);
-        int medium = (int)f2u(w4.w) - 1;
-        const DMaterial& M = medium_of(sc, medium);
-        float tmax = WAPT_TFAR;
-        uint32_t tri = trace_ray<false>(sc.tm, S, dir, WAPT_TRACE_BIAS, tmax, &s_stack[threadIdx.x], glane, tc);
-        rays++;
-        if (tri == 0xffffffffu) continue;
-        int obj, prim;
-        V3 Ng = tri_normal(sc.tm.tris, tri, &obj, &prim);
-        V3 hp = point_at(S, tmax, dir);
-        const DLight& L = sc.lights[light];
-        if (kind == 0) {
-            if (obj != light) continue;
-            V3 att = attenuation(M, mag(hp - S));
-            float alt = light_pdf(L, hp, S);
-            float mis = WAPT_MIS_CONST / (WAPT_MIS_CONST + alt);
-            if (mis != mis) mis = 1.0f;
-            add_rgb(q.sum, pixel, mis * (w * ld3(L.Li) * att));
-        } else {
-            if (obj != medium) continue;
-            V3 N = normalized(Ng);
-            float F;
-            V3 D1 = refract_dir(N, -dir, M.ior, &F);
-            if (is_zero(D1)) continue;
-            V3 dir1 = -D1;
-            if (!finite_dir(dir1)) continue;
-            float tmax1 = WAPT_TFAR;
-            uint32_t tri1 = trace_ray<false>(sc.tm, hp, dir1, WAPT_TRACE_BIAS, tmax1, &s_stack[threadIdx.x], glane, tc);
+    WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED + 64 * WAPT_FEED_STRIDE);
+    Trav t = {};
+    bool have_task = false, have_ray = false;
+    uint32_t task = 0;
+    int stage = 0;          // 1: the ray in flight is the refracted one
+    float seg0 = 0.f, F0 = 0.f;  // length of the first segment and Fresnel term at the surface
+    for (;;) {
+        uint32_t idx = feed.take(!have_task);
+        if (idx != 0xffffffffu) {
+            float4 a = q.PA[idx], b = q.PB[idx];
+            trav_begin(t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, WAPT_TFAR);
+            task = idx;
+            stage = 0;
+            have_task = have_ray = true;
             rays++;
-            if (tri1 == 0xffffffffu) continue;
-            int obj1 = (int)f2u(sc.tm.tris[(size_t)tri1 * 3 + 2].y);
-            if (obj1 != light) continue;
-            V3 hp1 = point_at(hp, tmax1, dir1);
-            V3 att = attenuation(sc.mats[sc.n_objects], mag(hp1 - hp)) * attenuation(M, mag(hp - S));
-            add_rgb(q.sum, pixel, (1.0f - F) * (w * ld3(L.Li) * att));
+        }
+        if (!__any(have_task)) break;
+        if (trav_step<false>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
+            have_ray = false;
+            have_task = false;
+            const uint32_t tri = t.hit;
+            if (tri != 0xffffffffu) {
+                const float tmax = trav_finish(sc.tm, t);
+                const V3 S = t.o, dir = t.d;
+                const uint32_t info = f2u(q.PB[task].w);
+                const float4 w4 = q.PC[task];
+                const int light = (int)(info & 0xffffu);
+                const int kind = (int)(info >> 16);
+                const int medium = (int)f2u(w4.w) - 1;
+                const DMaterial& M = medium_of(sc, medium);
+                const DLight& L = sc.lights[light];
+                const V3 w = v3(w4.x, w4.y, w4.z);
+                int obj, prim;
+                V3 Ng = tri_normal(sc.tm.tris, tri, &obj, &prim);
+                V3 hp = point_at(S, tmax, dir);
+                if (stage == 1) {
+                    if (obj == light) {
+                        V3 att = attenuation(sc.mats[sc.n_objects], mag(hp - S)) * attenuation(M, seg0);
+                        add_rgb(q.sum, f2u(q.PA[task].w), (1.0f - F0) * (w * ld3(L.Li) * att));
+                    }
+                } else if (kind == 0) {
+                    if (obj == light) {
+                        V3 att = attenuation(M, mag(hp - S));
+                        float alt = light_pdf(L, hp, S);
+                        float mis = WAPT_MIS_CONST / (WAPT_MIS_CONST + alt);
+                        if (mis != mis) mis = 1.0f;
+                        add_rgb(q.sum, f2u(q.PA[task].w), mis * (w * ld3(L.Li) * att));
+                    }
+                } else if (obj == medium) {
+                    V3 N = normalized(Ng);
+                    float F;
+                    V3 D1 = refract_dir(N, -dir, M.ior, &F);
+                    V3 dir1 = -D1;
+                    if (!is_zero(D1) && finite_dir(dir1)) {
+                        seg0 = mag(hp - S);
+                        F0 = F;
+                        trav_begin(t, hp, dir1, WAPT_TRACE_BIAS, WAPT_TFAR);
+                        stage = 1;
+                        have_task = have_ray = true;
+                        rays++;
+                    }
+                }
+            }
         }
     }
     rays = wave_sum(rays);
@@ -1029,8 +1047,8 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     s->sgrid = std::max(1u, cus * env_u32("WAPT_SBLOCKS_PER_CU", 2));  // 1024-thread blocks of the shading kernels
     HIPCHK_S(hipMalloc((void**)&s->d_cnt, CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK_S(hipMemset(s->d_cnt, 0, CNT_TOTAL * sizeof(uint32_t)));
-    HIPCHK_S(hipMalloc((void**)&s->d_rays, 8 * sizeof(unsigned long long)));
-    HIPCHK_S(hipMemset(s->d_rays, 0, 8 * sizeof(unsigned long long)));
+    HIPCHK_S(hipMalloc((void**)&s->d_rays, 16 * sizeof(unsigned long long)));
+    HIPCHK_S(hipMemset(s->d_rays, 0, 16 * sizeof(unsigned long long)));
     HIPCHK_S(hipHostMalloc((void**)&s->h_cnt, CNT_TOTAL * sizeof(uint32_t) + 64));
 
     memset(&s->ks, 0, sizeof(s->ks));
@@ -1238,6 +1256,9 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     kp.tilesX = (uint32_t)((W + 7) / 8);
     kp.slots_per_sample = kp.tilesX * (uint32_t)((H + 7) / 8) * 64u;
     kp.dense_raygen = (W % 8 == 0 && H % 8 == 0) ? 1 : 0;
+    kp.sample_count = (uint32_t)std::max(prm->sample_count, 1);
+    kp.pixel_major = (int32_t)env_u32("WAPT_PIXEL_MAJOR", 0);
+    kp.write_hits = s->has_scatter ? 1 : 0;
     KQueues q = s->kq;
     q.sum = d_sum;
     q.debug_pixel = env_u32("WAPT_DEBUG_PIXEL", 0xffffffffu);
@@ -1272,8 +1293,8 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     const unsigned long long total = (unsigned long long)kp.slots_per_sample * (unsigned long long)prm->sample_count;
     unsigned long long issued = 0;
     uint64_t rays_trace = 0, n_trace_launches = 0, n_shadow_launches = 0;
-    HIPCHK(hipMemsetAsync(s->d_rays, 0, 8 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, CNT_OVERFLOW, 0u);
+    HIPCHK(hipMemsetAsync(s->d_rays, 0, 16 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_OVERFLOW, 0u);
 
     for (;;) {
         int d = -1;
@@ -1285,7 +1306,7 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
         if (d < 0) {
             if (issued >= total) break;
             uint32_t n = (uint32_t)std::min<unsigned long long>(s->capR, total - issued);
-            hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, CNT_R0, kp.dense_raygen ? n : 0u);
+            hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_R0, kp.dense_raygen ? n : 0u);
             tm.run(FAM_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, sgrid, sblock, 0, st, ks, q, kp, issued, n); });
             issued += n;
             if (kp.dense_raygen) {
@@ -1300,25 +1321,23 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
         uint32_t n = std::min(have[d], chunk_for(d));
         uint32_t start = have[d] - n;
         have[d] = start;
-        hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, st, s->d_cnt, d < td ? CNT_R0 + d + 1 : -1, 0u);
+        hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, d < td ? CNT_R0 + d + 1 : -1, 0u);
         tm.run(FAM_TRACE, [&] {
             if (prm->profile & 2) hipLaunchKernelGGL(k_trace<true>, grid, block, 0, st, ks, q, d, start, n);
             else hipLaunchKernelGGL(k_trace<false>, grid, block, 0, st, ks, q, d, start, n);
         });
         rays_trace += n;
         n_trace_launches++;
-        tm.run(FAM_HEAD, [&] { hipLaunchKernelGGL(k_head, sgrid, sblock, 0, st, ks, q, kp, d, start, n); });
-        tm.run(FAM_SHADE, [&] {
-            hipLaunchKernelGGL(k_shade_lambert, sgrid, sblock, 0, st, ks, q, kp, d, start);
-            hipLaunchKernelGGL(k_shade_specular, sgrid, sblock, 0, st, ks, q, kp, d, start);
-            hipLaunchKernelGGL(k_shade_dielectric, sgrid, sblock, 0, st, ks, q, kp, d, start);
-        });
+        tm.run(FAM_SHADE, [&] { hipLaunchKernelGGL(k_surface, sgrid, sblock, 0, st, ks, q, kp, d, start, n); });
         if (s->has_scatter) {
             tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_volume, sgrid, sblock, 0, st, ks, q, kp, d, start); });
             tm.run(FAM_PROBE, [&] { hipLaunchKernelGGL(k_probe, grid, block, 0, st, ks, q); });
         }
         {
-            tm.run(FAM_SHADOW, [&] { hipLaunchKernelGGL(k_shadow, grid, block, 0, st, ks, q); });
+            tm.run(FAM_SHADOW, [&] {
+                if (prm->profile & 2) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, st, ks, q);
+                else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, st, ks, q);
+            });
         }
         n_shadow_launches++;
         if (d < td) {
@@ -1327,7 +1346,7 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
             have[d + 1] = std::min(s->h_cnt[CNT_R0 + d + 1], s->capR);
         }
     }
-    unsigned long long h_rays[8] = {0};
+    unsigned long long h_rays[16] = {0};
     HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(h_rays, s->d_rays, sizeof(h_rays), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1348,6 +1367,11 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
         stats->trace_wave_steps = h_rays[4];
         stats->trace_node_steps = h_rays[5];
         stats->trace_tri_trips = h_rays[6];
+        stats->shadow_node_visits = h_rays[8];
+        stats->shadow_tri_tests = h_rays[9];
+        stats->shadow_wave_steps = h_rays[10];
+        stats->shadow_node_steps = h_rays[11];
+        stats->shadow_tri_trips = h_rays[12];
         if (tm.on) {
             double ms[FAM_N] = {0};
             for (auto& r : tm.recs) {
@@ -1399,7 +1423,7 @@ extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint
                                      wapt_trace_counters* counters, float* ms) {
     if (!s || (n && (!d_rays || !d_hits))) return wapt_fail(WAPT_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipMemsetAsync(s->d_rays, 0, 8 * sizeof(unsigned long long), s->stream));
+    HIPCHK(hipMemsetAsync(s->d_rays, 0, 16 * sizeof(unsigned long long), s->stream));
     hipEvent_t a = nullptr, b = nullptr;
     if (ms) {
         HIPCHK(hipEventCreate(&a));
@@ -1412,7 +1436,7 @@ extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint
         if (rc) return rc;
         for (uint64_t off = 0; off < n; off += batch) {
             uint32_t m = (uint32_t)std::min<uint64_t>(batch, n - off);
-            hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s->stream, s->d_cnt, -1, 0u);
+            hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, s->stream, s->d_cnt, -1, 0u);
             const float4* r = (const float4*)d_rays + 2 * off;
             float* h = (float*)d_hits + 6 * off;
             if (counters)
