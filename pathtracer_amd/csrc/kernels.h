@@ -21,10 +21,7 @@
 #include "traverse.h"
 
 enum {
-    CNT_QL = 0,   // diffuse hits of the current step (indices into the step)
-    CNT_QS,       // specular hits
-    CNT_QD,       // dielectric / dielectricsss hits
-    CNT_QV,       // segments that scatter
+    CNT_QV = 3,   // segments of the current step that scatter (indices into the step)
     CNT_S,        // shadow-walk tasks
     CNT_P,        // probe tasks
     CNT_OVERFLOW, // traversal pushes dropped + queue pushes dropped (must stay 0)
@@ -49,7 +46,7 @@ struct KQueues {
     float4 *SA, *SB, *SC;
     float4 *PA, *PB, *PC;
     uint2* hits;             // (t bits, triangle) per task of the current step
-    uint32_t *QL, *QS, *QD, *QV;
+    uint32_t* QV;            // tasks of the current step whose segment is marched (scenes with media)
     uint32_t capR, capS, capP;
     uint32_t* cnt;           // CNT_*
     unsigned long long* rays;  // closest-hit queries issued by shadow and probe kernels
@@ -67,5 +64,6 @@ struct KParams {
     int32_t dense_raygen;       // W and H are multiples of 8: every slot is a pixel sample
     uint32_t sample_count;      // samples of this call
     int32_t write_hits;         // the scene has media: keep refined hits and the list of marched segments for k_volume
-    int32_t pixel_major;        // task order: all samples of a pixel next to each other (else sample by sample)
+    int32_t pixel_major;        // task order: all samples of a pixel next to each other (else sample by sample;
+                                // experiment: without pre-reduction the pixel sums then contend, see WAPT_PIXEL_MAJOR)
 };

@@ -1125,18 +1125,25 @@ int ensure_spill(wapt_scene* s) {
 // Capacities: large launches matter more than anything else for the traversal kernels (a launch ends
 // with a tail in which most lanes have run out of work: at 2^22 tasks per launch the lanes of the
 // closest-hit kernel were busy 55 % of the time, at 2^26 90 %), and HBM is plentiful, so the default
-// is 2^26 tasks per depth (3 GiB per depth) and 2^27 shadow / probe tasks for scenes with media, cut
-// down to what the call can use and to a quarter of the free device memory.
-int ensure_queues(wapt_scene* s, int td, uint64_t paths) {
+// is 2^26 tasks per depth (3 GiB per depth) and 2^29 shadow / probe tasks (24 GiB each) for scenes with
+// media, whose chunks are sized by the worst-case fan-out of a marched segment; all of it is cut down to
+// what the call can use and to a quarter of the free device memory.
+int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t shadows_per_task, uint64_t probes_per_task) {
     int depths = td + 1;
-    uint32_t capR = env_u32("WAPT_RAD_CAP", s->has_scatter ? (1u << 24) : (1u << 26));
+    uint32_t capR = env_u32("WAPT_RAD_CAP", 1u << 26);
     capR = (uint32_t)std::min<uint64_t>(capR, (paths + 4095) & ~(uint64_t)4095);
     capR = std::max(capR, 64u * 64u);
     capR &= ~63u;
-    uint32_t capS = env_u32("WAPT_SHADOW_CAP", s->has_scatter ? (1u << 27) : capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
-    uint32_t capP = env_u32("WAPT_PROBE_CAP", s->has_scatter ? (1u << 27) : 64u);
+    uint32_t capS = env_u32("WAPT_SHADOW_CAP", s->has_scatter ? (1u << 29) : capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
+    uint32_t capP = env_u32("WAPT_PROBE_CAP", s->has_scatter ? (1u << 29) : 64u);
+    if (s->has_scatter) {
+        // a call with few paths cannot fill more than its worst-case fan-out
+        auto need = [&](uint64_t per_task) { return std::max<uint64_t>(((paths + 4095) & ~(uint64_t)4095) * std::max<uint64_t>(per_task, 1), 1u << 16); };
+        capS = (uint32_t)std::min<uint64_t>(capS, need(shadows_per_task));
+        capP = (uint32_t)std::min<uint64_t>(capP, need(probes_per_task));
+    }
     auto footprint = [&](uint64_t r, uint64_t sh, uint64_t pr) {
-        return (uint64_t)depths * r * 48 + sh * 48 + pr * 48 + r * 24;
+        return (uint64_t)depths * r * 48 + sh * 48 + pr * 48 + r * 12;
     };
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -1167,7 +1174,7 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths) {
     size_t oSA = take((size_t)capS * 16), oSB = take((size_t)capS * 16), oSC = take((size_t)capS * 16);
     size_t oPA = take((size_t)capP * 16), oPB = take((size_t)capP * 16), oPC = take((size_t)capP * 16);
     size_t oH = take((size_t)capR * 8);
-    size_t oQL = take((size_t)capR * 4), oQS = take((size_t)capR * 4), oQD = take((size_t)capR * 4), oQV = take((size_t)capR * 4);
+    size_t oQV = take(s->has_scatter ? (size_t)capR * 4 : 256);
     HIPCHK(hipMalloc(&s->d_queue_block, bytes));
     char* b = (char*)s->d_queue_block;
     KQueues& q = s->kq;
@@ -1181,9 +1188,6 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths) {
     q.PB = (float4*)(b + oPB);
     q.PC = (float4*)(b + oPC);
     q.hits = (uint2*)(b + oH);
-    q.QL = (uint32_t*)(b + oQL);
-    q.QS = (uint32_t*)(b + oQS);
-    q.QD = (uint32_t*)(b + oQD);
     q.QV = (uint32_t*)(b + oQV);
     q.capR = capR;
     q.capS = capS;
@@ -1238,8 +1242,14 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     if (!(prm->mr >= 0.f) || !(prm->me >= 0.f)) return wapt_fail(WAPT_E_INVALID, "mr and me must be >= 0");
     HIPCHK(hipSetDevice(s->device));
     const uint64_t n_paths = (uint64_t)((s->ks.cam.resI + 7) / 8) * (uint64_t)((s->ks.cam.resJ + 7) / 8) * 64u * (uint64_t)prm->sample_count;
-    int rc = ensure_queues(s, prm->max_depth, n_paths);
-    if (rc) return rc;
+    {
+        // worst-case shadow / probe tasks one task of depth 0 can emit (see chunk_for below)
+        uint64_t r0 = s->has_scatter ? (uint64_t)((double)s->max_segment * prm->mr) + 1 : 0;
+        uint64_t sh = (uint64_t)s->n_lights * prm->lsamples * (1 + r0);
+        uint64_t pr = r0 * (uint64_t)s->n_lights * (s->has_inside ? 16 : 1);
+        int rc = ensure_queues(s, prm->max_depth, n_paths, sh, pr);
+        if (rc) return rc;
+    }
     auto t0 = std::chrono::steady_clock::now();
 
     const int td = prm->max_depth;
