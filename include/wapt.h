@@ -36,7 +36,8 @@ enum {
     WAPT_E_IO = 2,        /* file could not be read / parsed / written     */
     WAPT_E_HIP = 3,       /* a HIP runtime call failed                     */
     WAPT_E_NO_DEVICE = 4, /* no usable gfx950 device                       */
-    WAPT_E_LIMIT = 5      /* a documented capacity limit was exceeded      */
+    WAPT_E_LIMIT = 5,     /* a documented capacity limit was exceeded      */
+    WAPT_E_ABORTED = 6    /* wapt_progressive_abort() ended the call       */
 };
 
 /* Material flag bits: the booleans of struct wa_shader, src/objects.h:32-39. */
@@ -215,6 +216,42 @@ int wapt_intersect(wapt_scene* s, const wapt_ray* rays, uint32_t n, wapt_hit* hi
  * may be NULL) receives the HIP-event time of the kernel alone. */
 int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wapt_hit* d_hits,
                           wapt_trace_counters* counters, float* ms);
+
+/* ---- progressive rendering: the interactive-preview interface of udp_renderer -------------- */
+
+typedef struct wapt_progressive wapt_progressive;
+/* struct tile, src/unidirectionalPathTracer.h:14-18 */
+typedef struct wapt_tile {
+    int32_t l, r, b, t;
+    int32_t w, h;
+} wapt_tile;
+
+/* The accumulating state of udp_renderer (internalBuf + itCnt + render resolution + region,
+ * src/unidirectionalPathTracer.cpp:50-62): a display-sized running-average buffer on the scene's GPU.
+ * params->psamples is the number of samples one iteration adds; sample_begin/sample_count are ignored. */
+int wapt_progressive_create(wapt_scene* s, const wapt_render_params* params, wapt_progressive** out);
+void wapt_progressive_destroy(wapt_progressive* p);
+/* udp_renderer::reset, cpp:907-917: iteration count 0, buffer black. */
+int wapt_progressive_reset(wapt_progressive* p);
+/* udp_renderer::setIterationCount, cpp:919-922 (render() itself never changes the count, as in the
+ * reference: the caller advances it). */
+int wapt_progressive_set_iteration(wapt_progressive* p, int32_t iteration);
+/* udp_renderer::setRenderResolution + lowerResolution, cpp:68-76, 924-934: render at 1/2^k of the
+ * display resolution and replicate every pixel into a 2^k x 2^k block; resets the region. */
+int wapt_progressive_set_resolution(wapt_progressive* p, int32_t downres_pow2);
+/* udp_renderer::setRegion, cpp:962-972, in pixels of the render resolution: [l, r) x [b, t).  The
+ * reference stores the region but its render loop ignores it; here only the region is rendered. */
+int wapt_progressive_set_region(wapt_progressive* p, int32_t l, int32_t r, int32_t b, int32_t t);
+/* One iteration = udp_renderer::render with itCnt = n: psamples new samples per pixel of the region,
+ * internal = n/(n+1) internal + 1/(n+1) new (cpp:141-145), then the frame buffer (display size, host)
+ * receives the internal buffer with pixel replication (cpp:152-159).  Iteration n uses the global sample
+ * indices [n psamples, (n+1) psamples). */
+int wapt_progressive_render(wapt_progressive* p, float* fb, wapt_stats* stats);
+/* udp_renderer::abort, cpp:936-939, callable from another thread: the running iteration finishes the
+ * paths it has started, starts no more, leaves the running average untouched and returns WAPT_E_ABORTED. */
+int wapt_progressive_abort(wapt_progressive* p);
+/* udp_renderer::generateTiles, cpp:941-960: fills 4^level tiles, *n_out = their number. */
+int wapt_generate_tiles(int32_t renW, int32_t renH, int32_t subdiv_level, wapt_tile* tiles, int32_t* n_out);
 
 const char* wapt_last_error(void);
 const char* wapt_version(void);

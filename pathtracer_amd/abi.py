@@ -66,3 +66,7 @@ class TraceCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("stack_spills", C.c_uint64),
                 ("wave_steps", C.c_uint64), ("node_steps", C.c_uint64), ("tri_trips", C.c_uint64)]
+
+
+class Tile(C.Structure):  # wapt_tile
+    _fields_ = [("l", C.c_int32), ("r", C.c_int32), ("b", C.c_int32), ("t", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]

@@ -58,14 +58,38 @@ class udp_renderer {
         p_.sample_begin = 0;
         p_.sample_count = psamples;
     }
+    ~udp_renderer() { wapt_progressive_destroy(prog_); }
     void setSeed(uint64_t s) { p_.seed = s; }
+    // One call renders the whole image; once the progressive interface below has been touched it is one
+    // iteration of the running average instead (cpp:141-161).
     void render(float* buffer) {
         fb_ = buffer;
-        if (wapt_render(content_->handle(), &p_, fb_, &stats)) throw std::runtime_error(wapt_last_error());
+        int rc = prog_ ? wapt_progressive_render(prog_, fb_, &stats) : wapt_render(content_->handle(), &p_, fb_, &stats);
+        if (rc) throw std::runtime_error(wapt_last_error());
+    }
+    // progressive interface (src/unidirectionalPathTracer.h:40-47)
+    void reset() { chk(wapt_progressive_reset(prog())); }
+    void setIterationCount(int n) { chk(wapt_progressive_set_iteration(prog(), n)); }
+    void setRenderResolution(int downresFactorOf2) { chk(wapt_progressive_set_resolution(prog(), downresFactorOf2)); }
+    void setRegion(int l, int r, int b, int t) { chk(wapt_progressive_set_region(prog(), l, r, b, t)); }
+    void abort() { chk(wapt_progressive_abort(prog())); }
+    int generateTiles(int subdivLevel, wapt_tile* tiles) {
+        int resI, resJ, n = 0;
+        content_->getImageResolution(&resI, &resJ);
+        chk(wapt_generate_tiles(resI, resJ, subdivLevel, tiles, &n));
+        return n;
     }
     wapt_stats stats{};
   private:
+    static void chk(int rc) {
+        if (rc) throw std::runtime_error(wapt_last_error());
+    }
+    wapt_progressive* prog() {
+        if (!prog_) chk(wapt_progressive_create(content_->handle(), &p_, &prog_));
+        return prog_;
+    }
     wa_content* content_;
     float* fb_;
     wapt_render_params p_;
+    wapt_progressive* prog_ = nullptr;
 };

@@ -63,6 +63,7 @@ struct KParams {
     uint32_t tilesX;
     int32_t dense_raygen;       // W and H are multiples of 8: every slot is a pixel sample
     uint32_t sample_count;      // samples of this call
+    int32_t rl, rr, rb, rt;     // pixel rectangle [rl, rr) x [rb, rt) that is rendered (setRegion, cpp:962-972)
     int32_t write_hits;         // the scene has media: keep refined hits and the list of marched segments for k_volume
     int32_t pixel_major;        // task order: all samples of a pixel next to each other (else sample by sample;
                                 // experiment: without pre-reduction the pixel sums then contend, see WAPT_PIXEL_MAJOR)

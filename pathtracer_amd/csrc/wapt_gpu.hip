@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_raygen(KScene sc, KQueues q, KP
         uint32_t tile = r >> 6, within = r & 63u;
         int px = (int)((tile % p.tilesX) * 8u + (within & 7u));
         int py = (int)((tile / p.tilesX) * 8u + (within >> 3));
-        valid = valid && px < sc.cam.resI && py < sc.cam.resJ;
+        valid = valid && px < sc.cam.resI && py < sc.cam.resJ && px >= p.rl && px < p.rr && py >= p.rb && py < p.rt;
         uint32_t pixel = (uint32_t)(py * sc.cam.resI + px);
         uint32_t key = wapt_key_root(p.seed, (uint32_t)p.sample_begin + s_local);
         uint32_t stream = wapt_stream(key, pixel);
@@ -558,7 +560,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n = q.cnt[CNT_S];
+    uint32_t n = min(q.cnt[CNT_S], q.capS);
     TraceCount tc = {};
     uint32_t rays = 0;
     const int global_m = sc.n_objects;
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
 __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n = q.cnt[CNT_P];
+    uint32_t n = min(q.cnt[CNT_P], q.capP);
     TraceCount tc = {};
     uint32_t rays = 0;
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED + 64 * WAPT_FEED_STRIDE);
@@ -851,6 +853,7 @@ struct wapt_scene {
     bool has_scatter = false, has_inside = false;
     float max_segment = 0.f;
     int n_lights = 0;
+    wapt_camera camera;  // as described by the caller (the progressive interface re-derives lower resolutions from it)
     std::vector<hipEvent_t> ev_pool;
 };
 
@@ -1063,6 +1066,7 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     s->ks.n_lights = desc->n_lights;
     s->ks.n_objects = desc->n_objects;
     s->ks.cam = to_device(desc->camera);
+    s->camera = desc->camera;
     memcpy(s->ks.wc, desc->world_center, 12);
     s->ks.wr = desc->world_radius;
     memset(&s->kq, 0, sizeof(s->kq));
@@ -1233,7 +1237,23 @@ enum { FAM_RAYGEN, FAM_TRACE, FAM_HEAD, FAM_SHADE, FAM_VOLUME, FAM_SHADOW, FAM_P
 
 }  // namespace
 
+namespace {
+// What a render call looks at: the scene's camera and the whole image, unless the progressive
+// interface has lowered the resolution or set a region; `abort` is polled between launches.
+struct RenderView {
+    DCamera cam;
+    int l, r, b, t;  // pixel rectangle [l, r) x [b, t)
+    const std::atomic<int>* abort;
+};
+int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* d_sum, wapt_stats* stats, const RenderView* view);
+}  // namespace
+
 extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* prm, float* d_sum, wapt_stats* stats) {
+    return render_accumulate_view(s, prm, d_sum, stats, nullptr);
+}
+
+namespace {
+int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* d_sum, wapt_stats* stats, const RenderView* view) {
     if (!s || !prm || !d_sum) return wapt_fail(WAPT_E_INVALID, "null argument");
     if (prm->psamples <= 0 || prm->hsamples <= 0 || prm->lsamples <= 0)
         return wapt_fail(WAPT_E_INVALID, "psamples, hsamples and lsamples must be positive");
@@ -1241,7 +1261,9 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     if (prm->sample_begin < 0 || prm->sample_count < 0) return wapt_fail(WAPT_E_INVALID, "bad sample range");
     if (!(prm->mr >= 0.f) || !(prm->me >= 0.f)) return wapt_fail(WAPT_E_INVALID, "mr and me must be >= 0");
     HIPCHK(hipSetDevice(s->device));
-    const uint64_t n_paths = (uint64_t)((s->ks.cam.resI + 7) / 8) * (uint64_t)((s->ks.cam.resJ + 7) / 8) * 64u * (uint64_t)prm->sample_count;
+    KScene ks = s->ks;
+    if (view) ks.cam = view->cam;
+    const uint64_t n_paths = (uint64_t)((ks.cam.resI + 7) / 8) * (uint64_t)((ks.cam.resJ + 7) / 8) * 64u * (uint64_t)prm->sample_count;
     {
         // worst-case shadow / probe tasks one task of depth 0 can emit (see chunk_for below)
         uint64_t r0 = s->has_scatter ? (uint64_t)((double)s->max_segment * prm->mr) + 1 : 0;
@@ -1253,7 +1275,7 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     auto t0 = std::chrono::steady_clock::now();
 
     const int td = prm->max_depth;
-    const int W = s->ks.cam.resI, H = s->ks.cam.resJ;
+    const int W = ks.cam.resI, H = ks.cam.resJ;
     KParams kp;
     memset(&kp, 0, sizeof(kp));
     kp.hsamples = prm->hsamples;
@@ -1265,14 +1287,18 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     kp.sample_begin = prm->sample_begin;
     kp.tilesX = (uint32_t)((W + 7) / 8);
     kp.slots_per_sample = kp.tilesX * (uint32_t)((H + 7) / 8) * 64u;
-    kp.dense_raygen = (W % 8 == 0 && H % 8 == 0) ? 1 : 0;
+    kp.rl = view ? view->l : 0;
+    kp.rr = view ? view->r : W;
+    kp.rb = view ? view->b : 0;
+    kp.rt = view ? view->t : H;
+    const bool whole = kp.rl <= 0 && kp.rb <= 0 && kp.rr >= W && kp.rt >= H;
+    kp.dense_raygen = (W % 8 == 0 && H % 8 == 0 && whole) ? 1 : 0;
     kp.sample_count = (uint32_t)std::max(prm->sample_count, 1);
     kp.pixel_major = (int32_t)env_u32("WAPT_PIXEL_MAJOR", 0);
     kp.write_hits = s->has_scatter ? 1 : 0;
     KQueues q = s->kq;
     q.sum = d_sum;
     q.debug_pixel = env_u32("WAPT_DEBUG_PIXEL", 0xffffffffu);
-    const KScene& ks = s->ks;
     hipStream_t st = s->stream;
     const dim3 grid(s->grid), block(WAPT_BLOCK);
     const dim3 sgrid(s->sgrid), sblock(WAPT_SBLOCK);
@@ -1303,6 +1329,7 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     const unsigned long long total = (unsigned long long)kp.slots_per_sample * (unsigned long long)prm->sample_count;
     unsigned long long issued = 0;
     uint64_t rays_trace = 0, n_trace_launches = 0, n_shadow_launches = 0;
+    bool aborted = false;
     HIPCHK(hipMemsetAsync(s->d_rays, 0, 16 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_OVERFLOW, 0u);
 
@@ -1314,7 +1341,8 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
                 break;
             }
         if (d < 0) {
-            if (issued >= total) break;
+            if (view && view->abort && view->abort->load()) aborted = true;  // in-flight paths are finished, no new ones start
+            if (issued >= total || aborted) break;
             uint32_t n = (uint32_t)std::min<unsigned long long>(s->capR, total - issued);
             hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_R0, kp.dense_raygen ? n : 0u);
             tm.run(FAM_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, sgrid, sblock, 0, st, ks, q, kp, issued, n); });
@@ -1400,8 +1428,10 @@ extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* p
     }
     if (s->h_cnt[CNT_OVERFLOW])
         return wapt_fail(WAPT_E_LIMIT, "work dropped: " + std::to_string(s->h_cnt[CNT_OVERFLOW]) + " stack or queue overflows");
+    if (aborted) return wapt_fail(WAPT_E_ABORTED, "render aborted");
     return WAPT_OK;
 }
+}  // namespace
 
 __global__ void k_resolve(const float* sum, float* out, size_t n, float scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1427,6 +1457,174 @@ extern "C" int wapt_render(wapt_scene* s, const wapt_render_params* prm, float* 
     }
     (void)hipFree(d_sum);
     return rc;
+}
+
+// ---- progressive interface (udp_renderer::reset / setIterationCount / setRenderResolution / setRegion /
+// abort and the running average of renderTile, cpp:68-76, 141-161, 907-972)
+
+// internal = it/(it+1) * internal + 1/(it+1) * (sum / psamples) for the pixels of the region (cpp:141-145)
+__global__ void k_blend(float* avg, const float* sum, int renW, int dispW, int l, int r, int b, int t, float w_old, float w_new) {
+    int i = l + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = b + (int)blockIdx.y;
+    if (i >= r || j >= t) return;
+    size_t src = ((size_t)j * renW + i) * 3, dst = ((size_t)j * dispW + i) * 3;
+    for (int c = 0; c < 3; c++) avg[dst + c] = w_old * avg[dst + c] + w_new * sum[src + c];
+}
+
+// frame buffer block [i*rf, (i+1)*rf) x [j*rf, (j+1)*rf) <- internal(i, j) for the pixels of the region (cpp:152-159)
+__global__ void k_replicate(float* fb, const float* avg, int dispW, int dispH, int rf, int l, int r, int b, int t) {
+    int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), y = (int)blockIdx.y;
+    if (x >= dispW || y >= dispH) return;
+    int i = x / rf, j = y / rf;
+    if (i < l || i >= r || j < b || j >= t) return;
+    size_t src = ((size_t)j * dispW + i) * 3, dst = ((size_t)y * dispW + x) * 3;
+    for (int c = 0; c < 3; c++) fb[dst + c] = avg[src + c];
+}
+
+struct wapt_progressive {
+    wapt_scene* s = nullptr;
+    wapt_render_params prm;
+    wapt_camera cam;           // display camera
+    int dispW = 0, dispH = 0, renW = 0, renH = 0, rf = 1;
+    int l = 0, r = 0, b = 0, t = 0;
+    int it = 0;
+    float *d_avg = nullptr, *d_sum = nullptr, *d_fb = nullptr;  // display-sized
+    std::atomic<int> abort_flag{0};
+};
+
+extern "C" int wapt_progressive_create(wapt_scene* s, const wapt_render_params* prm, wapt_progressive** out) {
+    if (!s || !prm || !out) return wapt_fail(WAPT_E_INVALID, "null argument");
+    if (prm->psamples <= 0) return wapt_fail(WAPT_E_INVALID, "psamples must be positive");
+    HIPCHK(hipSetDevice(s->device));
+    std::unique_ptr<wapt_progressive> p(new wapt_progressive());
+    p->s = s;
+    p->prm = *prm;
+    p->cam = s->camera;
+    p->dispW = p->renW = s->camera.resI;
+    p->dispH = p->renH = s->camera.resJ;
+    p->r = p->renW;
+    p->t = p->renH;
+    size_t bytes = (size_t)p->dispW * p->dispH * 3 * sizeof(float);
+    HIPCHK(hipMalloc((void**)&p->d_avg, bytes));
+    HIPCHK(hipMalloc((void**)&p->d_sum, bytes));
+    HIPCHK(hipMalloc((void**)&p->d_fb, bytes));
+    HIPCHK(hipMemset(p->d_avg, 0, bytes));
+    HIPCHK(hipMemset(p->d_fb, 0, bytes));
+    *out = p.release();
+    return WAPT_OK;
+}
+
+extern "C" void wapt_progressive_destroy(wapt_progressive* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->s->device);
+    (void)hipFree(p->d_avg);
+    (void)hipFree(p->d_sum);
+    (void)hipFree(p->d_fb);
+    delete p;
+}
+
+extern "C" int wapt_progressive_reset(wapt_progressive* p) {
+    if (!p) return wapt_fail(WAPT_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(p->s->device));
+    p->it = 0;
+    HIPCHK(hipMemsetAsync(p->d_avg, 0, (size_t)p->dispW * p->dispH * 3 * sizeof(float), p->s->stream));
+    return WAPT_OK;
+}
+
+extern "C" int wapt_progressive_set_iteration(wapt_progressive* p, int32_t it) {
+    if (!p || it < 0) return wapt_fail(WAPT_E_INVALID, "bad iteration count");
+    p->it = it;
+    return WAPT_OK;
+}
+
+extern "C" int wapt_progressive_set_resolution(wapt_progressive* p, int32_t downres_pow2) {
+    if (!p || downres_pow2 < 0 || downres_pow2 > 12) return wapt_fail(WAPT_E_INVALID, "bad resolution exponent");
+    // lowerResolution (cpp:924-934)
+    int w_new = (int)((float)p->dispW / powf(2.0f, (float)downres_pow2));
+    int h_new = (int)((float)p->dispH / powf(2.0f, (float)downres_pow2));
+    if (w_new < 1 || h_new < 1) return wapt_fail(WAPT_E_INVALID, "resolution exponent too large for this image");
+    if ((p->dispW % w_new) != 0) w_new++;
+    if ((p->dispH % h_new) != 0) h_new++;
+    p->renW = w_new;
+    p->renH = h_new;
+    p->rf = 1 << downres_pow2;
+    p->l = p->b = 0;
+    p->r = w_new;
+    p->t = h_new;
+    return WAPT_OK;
+}
+
+extern "C" int wapt_progressive_set_region(wapt_progressive* p, int32_t l, int32_t r, int32_t b, int32_t t) {
+    if (!p) return wapt_fail(WAPT_E_INVALID, "null argument");
+    if (l < 0 || b < 0 || r > p->renW || t > p->renH || l >= r || b >= t)
+        return wapt_fail(WAPT_E_INVALID, "region outside the render resolution");
+    p->l = l;
+    p->r = r;
+    p->b = b;
+    p->t = t;
+    return WAPT_OK;
+}
+
+extern "C" int wapt_progressive_abort(wapt_progressive* p) {
+    if (!p) return wapt_fail(WAPT_E_INVALID, "null argument");
+    p->abort_flag.store(1);
+    return WAPT_OK;
+}
+
+extern "C" int wapt_progressive_render(wapt_progressive* p, float* fb, wapt_stats* stats) {
+    if (!p || !fb) return wapt_fail(WAPT_E_INVALID, "null argument");
+    wapt_scene* s = p->s;
+    HIPCHK(hipSetDevice(s->device));
+    p->abort_flag.store(0);
+    RenderView view;
+    wapt_camera cam = p->cam;
+    cam.resI = p->renW;
+    cam.resJ = p->renH;
+    view.cam = to_device(cam);  // wa_camera::setResolution (fundamentals.cpp:256-263)
+    view.l = p->l;
+    view.r = p->r;
+    view.b = p->b;
+    view.t = p->t;
+    view.abort = &p->abort_flag;
+    wapt_render_params prm = p->prm;
+    // every iteration draws its own block of sample indices, so iterations are independent estimates
+    long long begin = (long long)p->it * prm.psamples;
+    if (begin + prm.psamples > 0x7fffffffLL) return wapt_fail(WAPT_E_LIMIT, "sample index overflow");
+    prm.sample_begin = (int32_t)begin;
+    prm.sample_count = prm.psamples;
+    HIPCHK(hipMemsetAsync(p->d_sum, 0, (size_t)p->renW * p->renH * 3 * sizeof(float), s->stream));
+    int rc = render_accumulate_view(s, &prm, p->d_sum, stats, &view);
+    if (rc) return rc;
+    float itf = (float)p->it;
+    dim3 blk(256), g1((unsigned)((p->r - p->l + 255) / 256), (unsigned)(p->t - p->b));
+    hipLaunchKernelGGL(k_blend, g1, blk, 0, s->stream, p->d_avg, p->d_sum, p->renW, p->dispW, p->l, p->r, p->b, p->t,
+                       itf / (itf + 1.0f), (1.0f / (itf + 1.0f)) / (float)prm.psamples);
+    dim3 g2((unsigned)((p->dispW + 255) / 256), (unsigned)p->dispH);
+    hipLaunchKernelGGL(k_replicate, g2, blk, 0, s->stream, p->d_fb, p->d_avg, p->dispW, p->dispH, p->rf, p->l, p->r, p->b, p->t);
+    HIPCHK(hipMemcpyAsync(fb, p->d_fb, (size_t)p->dispW * p->dispH * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    return WAPT_OK;
+}
+
+// generateTiles (cpp:941-960): 2^level x 2^level tiles over renW x renH, the last row / column takes the remainder
+extern "C" int wapt_generate_tiles(int32_t renW, int32_t renH, int32_t subdiv_level, wapt_tile* tiles, int32_t* n_out) {
+    if (!tiles || !n_out || renW <= 0 || renH <= 0 || subdiv_level < 0 || subdiv_level > 12)
+        return wapt_fail(WAPT_E_INVALID, "bad argument");
+    int dim = 1 << subdiv_level;
+    int tw = (int)((float)renW / (float)dim), th = (int)((float)renH / (float)dim);
+    for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) {
+            wapt_tile& T = tiles[j * dim + i];
+            T.l = i * tw;
+            T.r = (i + 1) * tw;
+            T.b = j * th;
+            T.t = (j + 1) * th;
+            if (i == dim - 1) T.r = renW;
+            if (j == dim - 1) T.t = renH;
+            T.w = T.h = 0;  // the reference leaves w and h of generated tiles unset; they are zeroed here
+        }
+    *n_out = dim * dim;
+    return WAPT_OK;
 }
 
 extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wapt_hit* d_hits,

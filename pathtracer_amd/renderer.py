@@ -70,15 +70,23 @@ class udp_renderer:
         self.params.seed = seed
         self.params.sample_begin, self.params.sample_count = 0, psamples
         self.stats = abi.Stats()
+        self._prog = C.c_void_p()  # created by the first call of the progressive interface
 
     def render(self, buffer=None, profile=False):
-        """Fills ``buffer`` (float32 [H,W,3], created when None) with mean radiance and returns it."""
+        """Fills ``buffer`` (float32 [H,W,3], created when None) with mean radiance and returns it.
+
+        Once one of reset / setIterationCount / setRenderResolution / setRegion has been called, render() is one
+        iteration of the progressive interface, as in the reference (cpp:141-161): the buffer receives the
+        running average over the iterations so far."""
         W, H = self.content.scene.resolution
         if buffer is None:
             buffer = np.empty((H, W, 3), np.float32)
         if buffer.dtype != np.float32 or buffer.size != W * H * 3 or not buffer.flags.c_contiguous:
             raise ValueError("frame buffer must be contiguous float32 with W*H*3 elements")
         self.params.profile = int(profile)
+        if self._prog:
+            capi.check(capi.wapt_progressive_render(self._prog, buffer.ctypes.data, C.byref(self.stats)))
+            return buffer
         self.params.sample_begin, self.params.sample_count = 0, self.params.psamples
         capi.check(capi.wapt_render(self.content._h, C.byref(self.params), buffer.ctypes.data, C.byref(self.stats)))
         return buffer
@@ -90,6 +98,48 @@ class udp_renderer:
         self.params.sample_begin, self.params.sample_count = sample_begin, sample_count
         capi.check(capi.wapt_render_accumulate(self.content._h, C.byref(self.params), d_sum_ptr, C.byref(self.stats)))
         return self.stats
+
+
+    # ---- progressive interface (src/unidirectionalPathTracer.cpp:68-76, 907-972) ----------------------------
+
+    def _progressive(self):
+        if not self._prog:
+            capi.check(capi.wapt_progressive_create(self.content._h, C.byref(self.params), C.byref(self._prog)))
+        return self._prog
+
+    def reset(self):
+        capi.check(capi.wapt_progressive_reset(self._progressive()))
+
+    def setIterationCount(self, itCnt):
+        capi.check(capi.wapt_progressive_set_iteration(self._progressive(), itCnt))
+
+    def setRenderResolution(self, downresFactorOf2):
+        capi.check(capi.wapt_progressive_set_resolution(self._progressive(), downresFactorOf2))
+
+    def setRegion(self, l, r, b, t):
+        capi.check(capi.wapt_progressive_set_region(self._progressive(), l, r, b, t))
+
+    def abort(self):
+        capi.check(capi.wapt_progressive_abort(self._progressive()))
+
+    def generateTiles(self, subdivLevel, renW=None, renH=None):
+        """Tiles of udp_renderer::generateTiles as a list of (l, r, b, t)."""
+        W, H = self.content.scene.resolution
+        tiles = (abi.Tile * (4 ** subdivLevel))()
+        n = C.c_int32()
+        capi.check(capi.wapt_generate_tiles(renW or W, renH or H, subdivLevel, tiles, C.byref(n)))
+        return [(t.l, t.r, t.b, t.t) for t in tiles[:n.value]]
+
+    def close(self):
+        if self._prog:
+            capi.wapt_progressive_destroy(self._prog)
+            self._prog = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def tonemap(fb):

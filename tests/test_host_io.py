@@ -170,3 +170,24 @@ def test_cli_help_and_convert(tmp_path):
     assert len(v) == 48 and len(f) == 12
     out = subprocess.run([CLI, "--bogus"], capture_output=True, text=True)
     assert out.returncode != 0
+
+
+def test_generate_tiles_matches_reference_formula():
+    """udp_renderer::generateTiles (src/unidirectionalPathTracer.cpp:941-960): 2^k x 2^k tiles, integer tile size,
+    the last column / row takes the remainder."""
+    import ctypes as C
+    from pathtracer_amd import abi, capi
+    for (W, H, k) in [(600, 600, 0), (1920, 1080, 2), (61, 37, 3), (7, 5, 1)]:
+        dim = 2 ** k
+        tiles = (abi.Tile * (dim * dim))()
+        n = C.c_int32()
+        capi.check(capi.wapt_generate_tiles(W, H, k, tiles, C.byref(n)))
+        assert n.value == dim * dim
+        tw, th = int(W / dim), int(H / dim)
+        for i in range(dim):
+            for j in range(dim):
+                t = tiles[j * dim + i]
+                assert (t.l, t.b) == (i * tw, j * th)
+                assert t.r == (W if i == dim - 1 else (i + 1) * tw)
+                assert t.t == (H if j == dim - 1 else (j + 1) * th)
+    assert capi.wapt_generate_tiles(0, 5, 1, tiles, C.byref(n)) != 0
