@@ -24,7 +24,8 @@ enum {
     CNT_QV = 3,   // segments of the current step that scatter (indices into the step)
     CNT_S,        // shadow-walk tasks
     CNT_P,        // probe tasks
-    CNT_OVERFLOW, // traversal pushes dropped + queue pushes dropped (must stay 0)
+    CNT_OVERFLOW, // traversal-stack pushes dropped (must stay 0)
+    CNT_QOVERFLOW, // queue pushes dropped (must stay 0)
     CNT_FEED = 128, // 3 x 32 work-feed counters of k_trace, k_shadow and k_probe, 64 words apart (zeroed by k_reset)
     CNT_R0 = 8,   // CNT_R0 + d: tasks in R[d]
     CNT_TOTAL = 128 + 3 * 32 * 64

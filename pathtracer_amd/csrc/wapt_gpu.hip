@@ -100,7 +100,7 @@ __device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, 
     uint32_t slot = block_push(&q.cnt[CNT_R0 + depth_next], pred);
     if (!pred) return;
     if (slot >= q.capR) {
-        atomicAdd(&q.cnt[CNT_OVERFLOW], 1u);
+        atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
         return;
     }
     size_t k = (size_t)depth_next * q.capR + slot;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from
     uint32_t slot = block_push(&q.cnt[CNT_S], pred);
     if (!pred) return;
     if (slot >= q.capS) {
-        atomicAdd(&q.cnt[CNT_OVERFLOW], 1u);
+        atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
         return;
     }
     q.SA[slot] = make_float4(from.x, from.y, from.z, u2f(pixel));
@@ -128,7 +128,7 @@ __device__ __forceinline__ void push_probe(const KQueues& q, bool pred, V3 o, V3
     uint32_t slot = block_push(&q.cnt[CNT_P], pred);
     if (!pred) return;
     if (slot >= q.capP) {
-        atomicAdd(&q.cnt[CNT_OVERFLOW], 1u);
+        atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
         return;
     }
     q.PA[slot] = make_float4(o.x, o.y, o.z, u2f(pixel));
@@ -1261,9 +1261,8 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     if (prm->sample_begin < 0 || prm->sample_count < 0) return wapt_fail(WAPT_E_INVALID, "bad sample range");
     if (!(prm->mr >= 0.f) || !(prm->me >= 0.f)) return wapt_fail(WAPT_E_INVALID, "mr and me must be >= 0");
     HIPCHK(hipSetDevice(s->device));
-    KScene ks = s->ks;
-    if (view) ks.cam = view->cam;
-    const uint64_t n_paths = (uint64_t)((ks.cam.resI + 7) / 8) * (uint64_t)((ks.cam.resJ + 7) / 8) * 64u * (uint64_t)prm->sample_count;
+    const DCamera cam = view ? view->cam : s->ks.cam;
+    const uint64_t n_paths = (uint64_t)((cam.resI + 7) / 8) * (uint64_t)((cam.resJ + 7) / 8) * 64u * (uint64_t)prm->sample_count;
     {
         // worst-case shadow / probe tasks one task of depth 0 can emit (see chunk_for below)
         uint64_t r0 = s->has_scatter ? (uint64_t)((double)s->max_segment * prm->mr) + 1 : 0;
@@ -1272,6 +1271,8 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         int rc = ensure_queues(s, prm->max_depth, n_paths, sh, pr);
         if (rc) return rc;
     }
+    KScene ks = s->ks;  // (after ensure_queues: it sets the spill area and stack capacity of ks.tm)
+    ks.cam = cam;
     auto t0 = std::chrono::steady_clock::now();
 
     const int td = prm->max_depth;
@@ -1332,6 +1333,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     bool aborted = false;
     HIPCHK(hipMemsetAsync(s->d_rays, 0, 16 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_OVERFLOW, 0u);
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_QOVERFLOW, 0u);
 
     for (;;) {
         int d = -1;
@@ -1394,7 +1396,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         memset(stats, 0, sizeof(*stats));
         stats->paths = (uint64_t)W * H * (uint64_t)prm->sample_count;
         stats->rays = rays_trace + h_rays[0];
-        stats->stack_overflows = s->h_cnt[CNT_OVERFLOW];
+        stats->stack_overflows = s->h_cnt[CNT_OVERFLOW] + s->h_cnt[CNT_QOVERFLOW];
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
         stats->n_trace_launches = n_trace_launches;
         stats->n_trace_rays = rays_trace;
@@ -1426,8 +1428,9 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
             stats->ms_probe = ms[FAM_PROBE];
         }
     }
-    if (s->h_cnt[CNT_OVERFLOW])
-        return wapt_fail(WAPT_E_LIMIT, "work dropped: " + std::to_string(s->h_cnt[CNT_OVERFLOW]) + " stack or queue overflows");
+    if (s->h_cnt[CNT_OVERFLOW] || s->h_cnt[CNT_QOVERFLOW])
+        return wapt_fail(WAPT_E_LIMIT, "work dropped: " + std::to_string(s->h_cnt[CNT_OVERFLOW]) + " traversal-stack pushes, " +
+                                           std::to_string(s->h_cnt[CNT_QOVERFLOW]) + " queue pushes");
     if (aborted) return wapt_fail(WAPT_E_ABORTED, "render aborted");
     return WAPT_OK;
 }

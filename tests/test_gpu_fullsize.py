@@ -1,0 +1,77 @@
+"""The benchmark workload at its full size (dragonChrome, 871 218 triangles, 1920x1080) through properties that do
+not need a CPU render of the same size:
+
+  * linearity in the sample set: two renders of disjoint sample ranges add up to the render of their union
+    (float atomics reorder sums: 1e-4 relative + 1e-6 absolute per pixel);
+  * the same samples whatever the queue capacity (8 chunks instead of 1): same tolerance;
+  * resolution independence of the image mean: the mean radiance of the 1080p frame equals the mean of the CPU
+    checker's 160x90 frame of the same camera within 2 % (both are estimates of the same integral over the
+    sensor; 2 % covers the checker's noise at 64 spp);
+  * rays per path within 1 % of the checker's.
+"""
+import numpy as np
+import pytest
+
+import oracle_api
+from pathtracer_amd import renderer, scenes
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1920, 1080
+
+
+@pytest.fixture(scope="module")
+def content():
+    c = renderer.wa_content(scenes.dragon("chrome", res=(W, H)))
+    yield c
+    c.close()
+
+
+def _accumulate(content, ranges, psamples, seed=11):
+    import torch
+    r = renderer.udp_renderer(content, psamples, 1, 1, 1, seed=seed)
+    acc = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
+    rays = 0
+    for (b, n) in ranges:
+        st = r.render_accumulate(acc.data_ptr(), b, n)
+        assert st.stack_overflows == 0
+        rays += st.rays
+    torch.cuda.synchronize()
+    return (acc / psamples).cpu().numpy().reshape(H, W, 3), rays
+
+
+def test_full_size_linearity_and_chunking(content, monkeypatch):
+    whole, rays = _accumulate(content, [(0, 8)], 8)
+    assert np.isfinite(whole).all()
+    parts, rays2 = _accumulate(content, [(0, 3), (3, 5)], 8)
+    np.testing.assert_allclose(parts, whole, rtol=1e-4, atol=1e-6)
+    assert rays2 == rays
+
+
+def test_full_size_small_queues_same_image(monkeypatch):
+    c = renderer.wa_content(scenes.dragon("chrome", res=(W, H)))
+    try:
+        ref, rays = _accumulate(c, [(0, 4)], 4)
+    finally:
+        c.close()
+    monkeypatch.setenv("WAPT_RAD_CAP", str(1 << 20))  # 8 chunks of the 8.3 M paths
+    c = renderer.wa_content(scenes.dragon("chrome", res=(W, H)))
+    try:
+        got, rays2 = _accumulate(c, [(0, 4)], 4)
+    finally:
+        c.close()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-6)
+    assert rays2 == rays
+
+
+def test_full_size_mean_and_rays_per_path_match_checker(content):
+    img, rays = _accumulate(content, [(0, 16)], 16, seed=23)
+    o = oracle_api.OracleScene(scenes.dragon("chrome", res=(160, 90)))
+    ref = o.render(64, 1, 1, seed=5, threads=16)
+    m_gpu, m_ref = img.reshape(-1, 3).mean(0), ref.reshape(-1, 3).mean(0)
+    print("mean gpu", m_gpu, "checker", m_ref)
+    np.testing.assert_allclose(m_gpu, m_ref, rtol=0.02)
+    rpp_gpu = rays / (W * H * 16.0)
+    rpp_ref = o.rays / (160 * 90 * 64.0)
+    print("rays/path gpu", rpp_gpu, "checker", rpp_ref)
+    assert abs(rpp_gpu - rpp_ref) <= 0.01 * rpp_ref
