@@ -59,7 +59,8 @@ class Hit(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_tris", C.c_uint64), ("node_bytes", C.c_uint64), ("tri_bytes", C.c_uint64),
-                ("node_size", C.c_uint32), ("tri_size", C.c_uint32), ("max_depth", C.c_uint32), ("sah_cost", C.c_float)]
+                ("node_size", C.c_uint32), ("tri_size", C.c_uint32), ("max_depth", C.c_uint32), ("sah_cost", C.c_float),
+                ("builder", C.c_uint32), ("build_seconds", C.c_float)]
 
 
 class TraceCounters(C.Structure):
@@ -70,3 +71,5 @@ class TraceCounters(C.Structure):
 
 class Tile(C.Structure):  # wapt_tile
     _fields_ = [("l", C.c_int32), ("r", C.c_int32), ("b", C.c_int32), ("t", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+BUILDER_AUTO, BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH = 0, 1, 2

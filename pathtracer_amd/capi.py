@@ -54,6 +54,7 @@ wapt_convert_obj_to_fast = _proto("wapt_convert_obj_to_fast", C.c_int, C.c_char_
 wapt_tonemap = _proto("wapt_tonemap", C.c_int, vp, C.c_int32, C.c_int32)
 wapt_write_bmp = _proto("wapt_write_bmp", C.c_int, C.c_char_p, C.c_int32, C.c_int32, vp)
 wapt_scene_create = _proto("wapt_scene_create", C.c_int, P(abi.SceneDesc), C.c_int32, P(vp))
+wapt_scene_create_with = _proto("wapt_scene_create_with", C.c_int, P(abi.SceneDesc), C.c_int32, C.c_int32, P(vp))
 wapt_scene_destroy = _proto("wapt_scene_destroy", None, vp)
 wapt_scene_bvh_info = _proto("wapt_scene_bvh_info", C.c_int, vp, P(abi.BvhInfo))
 wapt_render = _proto("wapt_render", C.c_int, vp, P(abi.RenderParams), vp, P(abi.Stats))
@@ -73,7 +74,8 @@ wapt_generate_tiles = _proto("wapt_generate_tiles", C.c_int, C.c_int32, C.c_int3
 
 EXPORTS = [
     "wapt_last_error", "wapt_version", "wapt_waff_load", "wapt_waff_desc", "wapt_waff_settings", "wapt_waff_free",
-    "wapt_convert_obj_to_fast", "wapt_tonemap", "wapt_write_bmp", "wapt_scene_create", "wapt_scene_destroy",
+    "wapt_convert_obj_to_fast", "wapt_tonemap", "wapt_write_bmp", "wapt_scene_create", "wapt_scene_create_with",
+    "wapt_scene_destroy",
     "wapt_scene_bvh_info", "wapt_render", "wapt_render_accumulate", "wapt_intersect", "wapt_intersect_device",
     "wapt_progressive_create", "wapt_progressive_destroy", "wapt_progressive_reset", "wapt_progressive_set_iteration",
     "wapt_progressive_set_resolution", "wapt_progressive_set_region", "wapt_progressive_render",

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "bvh8.h"
+#include "bvh_device.h"
 #include "kernels.h"
 #include "wapt_internal.h"
 
@@ -838,6 +839,8 @@ struct wapt_scene {
     uint64_t n_nodes = 0, n_tris = 0;
     uint32_t bvh_depth = 0;
     float sah = 0.f;
+    int builder = 0;
+    float build_seconds = 0.f;
     KScene ks;
     // owned device memory
     void *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_spill = nullptr;
@@ -967,21 +970,28 @@ int validate_desc(const wapt_scene_desc* d) {
 }  // namespace
 
 extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wapt_scene** out) {
+    return wapt_scene_create_with(desc, device, WAPT_BUILDER_AUTO, out);
+}
+
+extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_t builder, wapt_scene** out) {
     if (!out) return wapt_fail(WAPT_E_INVALID, "null output");
     *out = nullptr;
     int rc = validate_desc(desc);
     if (rc) return rc;
+    if (builder != WAPT_BUILDER_AUTO && builder != WAPT_BUILDER_HOST_SAH && builder != WAPT_BUILDER_DEVICE_LBVH)
+        return wapt_fail(WAPT_E_INVALID, "unknown BVH builder");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return wapt_fail(WAPT_E_NO_DEVICE, "no HIP device: this library has no CPU path");
     if (device < 0 || device >= ndev) return wapt_fail(WAPT_E_INVALID, "device index out of range");
-
-    Bvh8 bvh;
-    const char* err = nullptr;
-    if (!bvh8_build(desc->tri_verts, desc->tri_obj, desc->tri_prim, desc->n_tris, &bvh, &err))
-        return wapt_fail(WAPT_E_INVALID, std::string("BVH build: ") + err);
-    if (bvh.max_depth > WAPT_STACK_CAP)
-        return wapt_fail(WAPT_E_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(bvh.max_depth) + ")");
+    if (builder == WAPT_BUILDER_AUTO) {
+        // the SAH tree traces faster, the device build is the one that stays in seconds for huge scenes
+        const char* e = getenv("WAPT_BVH_BUILDER");
+        if (e && !strcmp(e, "device")) builder = WAPT_BUILDER_DEVICE_LBVH;
+        else if (e && !strcmp(e, "host")) builder = WAPT_BUILDER_HOST_SAH;
+        else builder = desc->n_tris >= (uint64_t)env_u32("WAPT_DEVICE_BUILD_MIN_TRIS", 1u << 24) ? WAPT_BUILDER_DEVICE_LBVH
+                                                                                                 : WAPT_BUILDER_HOST_SAH;
+    }
 
     HIPCHK(hipSetDevice(device));
     auto s = new wapt_scene();
@@ -997,16 +1007,48 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     } while (0)
 
     HIPCHK_S(hipStreamCreate(&s->stream));
-    s->n_nodes = bvh.nodes.size();
-    s->n_tris = bvh.tris.size();
-    s->bvh_depth = bvh.max_depth;
-    s->sah = bvh.sah_cost;
-    // bit 0 of a triangle's last word: its object is opaque (lets shadow walks stop at the first such hit)
-    for (auto& T : bvh.tris) T.pad = (desc->materials[T.obj].flags & WAPT_MAT_OPAQUE) ? 1u : 0u;
-    HIPCHK_S(hipMalloc(&s->d_nodes, bvh.nodes.size() * sizeof(Bvh8Node)));
-    HIPCHK_S(hipMalloc(&s->d_tris, bvh.tris.size() * sizeof(Bvh8Tri)));
-    HIPCHK_S(hipMemcpy(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice));
-    HIPCHK_S(hipMemcpy(s->d_tris, bvh.tris.data(), bvh.tris.size() * sizeof(Bvh8Tri), hipMemcpyHostToDevice));
+    auto tb0 = std::chrono::steady_clock::now();
+    float blo[3], bhi[3];
+    if (builder == WAPT_BUILDER_DEVICE_LBVH) {
+        std::vector<uint8_t> opaque((size_t)desc->n_objects);
+        for (int i = 0; i < desc->n_objects; i++) opaque[i] = (desc->materials[i].flags & WAPT_MAT_OPAQUE) ? 1 : 0;
+        DeviceBvh8 db;
+        std::string berr;
+        if (!bvh8_build_device(desc->tri_verts, desc->tri_obj, desc->tri_prim, desc->n_tris, opaque.data(),
+                               (uint32_t)desc->n_objects, s->stream, &db, &berr))
+            return bail(wapt_fail(WAPT_E_INVALID, "device BVH build: " + berr));
+        s->d_nodes = db.d_nodes;
+        s->d_tris = db.d_tris;
+        s->n_nodes = db.n_nodes;
+        s->n_tris = db.n_tris;
+        s->bvh_depth = db.max_depth;
+        s->sah = db.sah_cost;
+        memcpy(blo, db.lo, 12);
+        memcpy(bhi, db.hi, 12);
+        if (s->bvh_depth > WAPT_STACK_CAP)
+            return bail(wapt_fail(WAPT_E_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(s->bvh_depth) + ")"));
+    } else {
+        Bvh8 bvh;
+        const char* err = nullptr;
+        if (!bvh8_build(desc->tri_verts, desc->tri_obj, desc->tri_prim, desc->n_tris, &bvh, &err))
+            return bail(wapt_fail(WAPT_E_INVALID, std::string("BVH build: ") + err));
+        if (bvh.max_depth > WAPT_STACK_CAP)
+            return bail(wapt_fail(WAPT_E_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(bvh.max_depth) + ")"));
+        s->n_nodes = bvh.nodes.size();
+        s->n_tris = bvh.tris.size();
+        s->bvh_depth = bvh.max_depth;
+        s->sah = bvh.sah_cost;
+        memcpy(blo, bvh.lo, 12);
+        memcpy(bhi, bvh.hi, 12);
+        // bit 0 of a triangle's last word: its object is opaque (lets shadow walks stop at the first such hit)
+        for (auto& T : bvh.tris) T.pad = (desc->materials[T.obj].flags & WAPT_MAT_OPAQUE) ? 1u : 0u;
+        HIPCHK_S(hipMalloc(&s->d_nodes, bvh.nodes.size() * sizeof(Bvh8Node)));
+        HIPCHK_S(hipMalloc(&s->d_tris, bvh.tris.size() * sizeof(Bvh8Tri)));
+        HIPCHK_S(hipMemcpy(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice));
+        HIPCHK_S(hipMemcpy(s->d_tris, bvh.tris.data(), bvh.tris.size() * sizeof(Bvh8Tri), hipMemcpyHostToDevice));
+    }
+    s->builder = builder;
+    s->build_seconds = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
 
     std::vector<DMaterial> mats((size_t)desc->n_objects + 1);
     for (int i = 0; i < desc->n_objects; i++) mats[i] = to_device(desc->materials[i]);
@@ -1032,9 +1074,9 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     {
         double rb = desc->world_radius;
         for (int cx = 0; cx < 8; cx++) {
-            double dx = ((cx & 1) ? bvh.hi[0] : bvh.lo[0]) - desc->world_center[0];
-            double dy = ((cx & 2) ? bvh.hi[1] : bvh.lo[1]) - desc->world_center[1];
-            double dz = ((cx & 4) ? bvh.hi[2] : bvh.lo[2]) - desc->world_center[2];
+            double dx = ((cx & 1) ? bhi[0] : blo[0]) - desc->world_center[0];
+            double dy = ((cx & 2) ? bhi[1] : blo[1]) - desc->world_center[1];
+            double dz = ((cx & 4) ? bhi[2] : blo[2]) - desc->world_center[2];
             rb = std::max(rb, std::sqrt(dx * dx + dy * dy + dz * dz));
         }
         double dx = desc->camera.P[0] - desc->world_center[0], dy = desc->camera.P[1] - desc->world_center[1],
@@ -1104,6 +1146,8 @@ extern "C" int wapt_scene_bvh_info(const wapt_scene* s, wapt_bvh_info* o) {
     o->tri_bytes = s->n_tris * sizeof(Bvh8Tri);
     o->max_depth = s->bvh_depth;
     o->sah_cost = s->sah;
+    o->builder = (uint32_t)s->builder;
+    o->build_seconds = s->build_seconds;
     return WAPT_OK;
 }
 

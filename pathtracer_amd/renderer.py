@@ -16,12 +16,14 @@ from .scene import Scene
 class wa_content:
     """Scene resident on one GPU (BVH built by the library on the host at construction)."""
 
-    def __init__(self, scene: Scene, device: int = 0):
+    def __init__(self, scene: Scene, device: int = 0, builder: str = "auto"):
+        """builder: "auto" (host SAH below 2^24 triangles, device LBVH above), "host" or "device"."""
         self.scene = scene
         self.device = device
         self._h = C.c_void_p()
         d = scene.desc()
-        capi.check(capi.wapt_scene_create(C.byref(d), device, C.byref(self._h)))
+        b = {"auto": abi.BUILDER_AUTO, "host": abi.BUILDER_HOST_SAH, "device": abi.BUILDER_DEVICE_LBVH}[builder]
+        capi.check(capi.wapt_scene_create_with(C.byref(d), device, b, C.byref(self._h)))
 
     def getImageResolution(self):
         return self.scene.resolution

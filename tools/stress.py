@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--res", default="3840x2160")
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--builder", default="auto", choices=["auto", "host", "device"])
     args = ap.parse_args()
     import torch
     from pathtracer_amd import renderer, scenes
@@ -20,7 +21,7 @@ def main():
     sc = scenes.stress(res=(W, H), copies=args.copies)
     t_mesh = time.time() - t0
     t0 = time.time()
-    content = renderer.wa_content(sc, device=0)
+    content = renderer.wa_content(sc, device=0, builder=args.builder)
     t_build = time.time() - t0
     info = content.bvh_info()
     r = renderer.udp_renderer(content, psamples=args.spp, hsamples=1, lsamples=1, seed=7)
@@ -34,7 +35,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.time() - t0) / args.steps
     img = (acc / (args.spp * args.steps)).cpu()
-    out = {"copies": args.copies, "triangles": int(info.n_tris), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.max_depth),
+    out = {"copies": args.copies, "triangles": int(info.n_tris), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.max_depth), "builder": int(info.builder), "build_s": round(float(info.build_seconds), 2), "sah": float(info.sah_cost),
            "bvh_gb": (info.node_bytes + info.tri_bytes) / 1e9, "mesh_s": round(t_mesh, 1), "scene_create_s": round(t_build, 1),
            "res": args.res, "spp": args.spp, "seconds": dt, "mpaths_per_s": W * H * args.spp / dt / 1e6,
            "mrays_per_s": st.rays / dt / 1e6, "rays_per_path": st.rays / (W * H * args.spp), "stack_overflows": int(st.stack_overflows),
