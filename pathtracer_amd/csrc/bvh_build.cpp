@@ -18,6 +18,7 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <thread>
@@ -68,7 +69,8 @@ struct Builder2 {
     std::atomic<int> threads_free{0};
 
     static constexpr int BINS = 16;
-    static constexpr float C_TRAV = 0.5f;
+    float C_TRAV = 0.5f;   // cost of a node visit relative to a triangle test
+    int max_leaf = 3;      // the leaf record counts triangles in unary in 3 bits
 
     void build_range(uint32_t node, uint32_t b, uint32_t e) {
         // iterative on the right child, recursive (or threaded) on the left
@@ -135,7 +137,7 @@ struct Builder2 {
                 }
             }
             float area = bb.area();
-            if (cnt <= 3) {
+            if (cnt <= (uint32_t)max_leaf) {
                 float leaf_cost = area * cnt;
                 float split_cost = (best_axis >= 0) ? C_TRAV * area + best : FLT_MAX;
                 if (leaf_cost <= split_cost) {
@@ -225,6 +227,8 @@ bool bvh8_build(const float* verts, const int32_t* obj, const int32_t* prim, uin
         for (int a = 0; a < 3; a++) B.cent[3 * t + a] = 0.5f * (b.lo[a] + b.hi[a]);
         B.idx[t] = (uint32_t)t;
     }
+    if (const char* e = getenv("WAPT_BVH_MAX_LEAF")) B.max_leaf = std::min(3, std::max(1, atoi(e)));
+    if (const char* e = getenv("WAPT_BVH_CTRAV")) B.C_TRAV = (float)atof(e);
     B.nodes.resize(2 * n + 1);
     B.next = 1;
     unsigned hw = std::thread::hardware_concurrency();

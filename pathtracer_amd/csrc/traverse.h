@@ -113,7 +113,8 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
     const float tiny = 1e-18f;
     t.o = o;
     t.d = d;
-#ifdef WAPT_FAST_RCP
+#ifndef WAPT_EXACT_DIV
+    // 1-ulp reciprocals: the box test is not exact either way (quantised, conservative boxes)
     t.idx = __builtin_amdgcn_rcpf(fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
     t.idy = __builtin_amdgcn_rcpf(fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
     t.idz = __builtin_amdgcn_rcpf(fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
@@ -240,7 +241,13 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
             float V = dot(R, e1) * sgn;
             float Tn = dot(Ng, Cv) * sgn;
             if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * t.tmin < Tn && Tn <= absDen * t.tmax) {
-                t.tmax = __fdividef(Tn, absDen);  // fp32 while searching, like Embree; see refine_distance
+#ifdef WAPT_EXACT_DIV
+                t.tmax = Tn / absDen;
+#else
+                // search distance only (the final one is re-evaluated in fp64, see refine_distance): the
+                // 1-ulp reciprocal saves the ten-instruction IEEE division in the hottest loop
+                t.tmax = Tn * __builtin_amdgcn_rcpf(absDen);
+#endif
                 t.hit = ti;
                 if (SHADOW && (__float_as_uint(c.w) & 1u) && Tn < absDen * t.tblock) {
                     t.G = make_uint2(0u, 0u);
