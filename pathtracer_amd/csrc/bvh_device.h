@@ -17,7 +17,7 @@ struct DeviceBvh8 {
 };
 
 // verts: 9 floats per triangle (host); obj / prim: ids per triangle (host; prim may be null = running
-// index); obj_opaque[o] = 1 when object o is opaque (goes into bit 0 of the triangle record's last word).
+// index); obj_opaque[o] = flag byte of object o (goes into the low byte of the triangle record's last word, the object index above it).
 // The current device must be the one the scene lives on.  Returns false and fills err on failure.
 bool bvh8_build_device(const float* verts, const int32_t* obj, const int32_t* prim, uint64_t n, const uint8_t* obj_opaque,
                        uint32_t n_objects, hipStream_t st, DeviceBvh8* out, std::string* err);

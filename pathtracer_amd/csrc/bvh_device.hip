@@ -366,7 +366,7 @@ __global__ void k_collapse(Tree2 T, const uint32_t* __restrict__ refs, uint32_t 
                 }
                 tr.obj = obj[t];
                 tr.prim = prim ? prim[t] : (int32_t)t;
-                tr.pad = opaque[tr.obj];
+                tr.pad = (uint32_t)opaque[tr.obj] | ((uint32_t)tr.obj << 8);
                 out.tris[tbase + tri_off + j] = tr;
             }
             tri_off += c;

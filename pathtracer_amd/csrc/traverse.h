@@ -28,6 +28,11 @@
 #define WAPT_SHADOW_WAVES 5
 #endif
 
+// Last word of a triangle record: flags of its object in the low byte, the object index above.
+#define WAPT_TRI_OPAQUE 1u   // the object is opaque: a shadow walk that meets it before its end point is over
+#define WAPT_TRI_PLAIN 2u    // opaque, clear inside and no dielectric: reaching it AT the end point changes nothing
+#define WAPT_TRI_OBJ_SHIFT 8
+
 struct TraceMem {
     const uint4* __restrict__ nodes;   // 5 x uint4 per node
     const float4* __restrict__ tris;   // 3 x float4 per triangle
@@ -106,7 +111,9 @@ struct Trav {
     uint2 G;        // current node group
     uint2 T;        // pending triangles: first index, hit bits
     int sp;
-    float tblock;   // shadow walks: an OPAQUE surface hit closer than this ends the search at once
+    float tblock;   // shadow walks: an OPAQUE surface hit closer than this ends the search at once;
+                    // negative afterwards: the search was ended that way
+    uint32_t hflag; // shadow walks: last word of the hit triangle's record (flags | object << 8)
 };
 
 __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, float tmax) {
@@ -131,6 +138,7 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
     t.T = make_uint2(0u, 0u);
     t.sp = 0;
     t.tblock = 0.f;
+    t.hflag = 0u;
 }
 
 // One traversal step of a wave.  A lane without pending triangles visits its nearest pending inner
@@ -223,6 +231,9 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
             uint32_t ti = t.T.x + k;
             const float4* tp = m.tris + (size_t)ti * 3;
             float4 a = tp[0], b = tp[1], c = tp[2];
+            // (the flag word is only looked at for accepted hits: without this the compiler moves its load
+            //  into that branch, where a whole memory round trip is then waited for with most lanes idle)
+            if (SHADOW) asm volatile("" ::"v"(c.w));
             if (COUNT) cnt.tris++;
             // Ray/triangle test in the form Embree 3 uses for its default (non-robust) triangle
             // intersector (kernels/geometry/triangle_intersector_moeller.h, Moeller-Trumbore with
@@ -249,10 +260,14 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
                 t.tmax = Tn * __builtin_amdgcn_rcpf(absDen);
 #endif
                 t.hit = ti;
-                if (SHADOW && (__float_as_uint(c.w) & 1u) && Tn < absDen * t.tblock) {
-                    t.G = make_uint2(0u, 0u);
-                    t.sp = 0;
-                    bits = 0u;
+                if (SHADOW) {
+                    t.hflag = __float_as_uint(c.w);
+                    if ((t.hflag & WAPT_TRI_OPAQUE) && Tn < absDen * t.tblock) {
+                        t.G = make_uint2(0u, 0u);
+                        t.sp = 0;
+                        bits = 0u;
+                        t.tblock = -1.0f;
+                    }
                 }
             }
         }

@@ -27,7 +27,9 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 // (One returning atomic per wave on a single counter tops out near 90 per microsecond on this
 // chip, far below what the streaming kernels need; one per 1024-thread block is 16x fewer.)
 // Every thread of the block must call this together.
+#ifndef WAPT_SBLOCK
 #define WAPT_SBLOCK 1024
+#endif
 __device__ __forceinline__ uint32_t block_push(uint32_t* counter, bool pred) {
     __shared__ uint32_t s_cnt[WAPT_SBLOCK / 64];
     __shared__ uint32_t s_off[WAPT_SBLOCK / 64];
@@ -110,7 +112,15 @@ __device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, 
     q.RC[k] = make_float4(beta.x, beta.y, beta.z, u2f(key));
 }
 
-__device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from, V3 to, V3 w, uint32_t pixel) {
+// `target`: 0, or 1 + the index of the area light whose quad `to` was sampled on when the walk arrives
+// at that quad steeply enough for its last hit to be decided without a second look (see k_shadow).
+__device__ __forceinline__ uint32_t shadow_target(const DLight& L, int l, V3 from, V3 to) {
+    if (L.type != 0) return 0u;
+    V3 wi = normalized(to - from);
+    return fabsf(dot(wi, ld3(L.N))) >= 0.25f ? (uint32_t)l + 1u : 0u;
+}
+
+__device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from, V3 to, V3 w, uint32_t pixel, uint32_t target) {
     pred = pred && !(w.x == 0.f && w.y == 0.f && w.z == 0.f);
     uint32_t slot = block_push(&q.cnt[CNT_S], pred);
     if (!pred) return;
@@ -119,7 +129,7 @@ __device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from
         return;
     }
     q.SA[slot] = make_float4(from.x, from.y, from.z, u2f(pixel));
-    q.SB[slot] = make_float4(to.x, to.y, to.z, 0.f);
+    q.SB[slot] = make_float4(to.x, to.y, to.z, u2f(target));
     q.SC[slot] = make_float4(w.x, w.y, w.z, 0.f);
 }
 
@@ -383,6 +393,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_surface(KScene sc, KQueues q, K
             for (int s = 0; s < p.lsamples; s++) {
                 bool emit = false;
                 V3 LP = v3(0, 0, 0), wt = v3(0, 0, 0);
+                uint32_t tgt = 0u;
                 if (lambert) {
                     uint32_t dim = WAPT_DIM_NEE + 2u * (uint32_t)(l * p.lsamples + s);
                     float rpdf;
@@ -394,11 +405,12 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_surface(KScene sc, KQueues q, K
                             float sc_ = rls * (1.0f / WAPT_PI) * ndw * rpdf;
                             wt = sc_ * (w * kd * ld3(L.Li));
                             emit = true;
+                            if (L.type == 0 && fabsf(dot(Wi, ld3(L.N))) >= 0.25f) tgt = (uint32_t)l + 1u;
                         }
                     }
                     DBG(c.pixel, "nee d=%d key=%08x emit=%d LP=(%.5f %.5f %.5f) wt=%g\n", depth, c.key, (int)emit, LP.x, LP.y, LP.z, wt.x);
                 }
-                push_shadow(q, emit, c.P, LP, wt, c.pixel);
+                push_shadow(q, emit, c.P, LP, wt, c.pixel, tgt);
             }
         }
         // children: hsamples uniform hemisphere directions of a Lambert event (no emission at the next
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KP
                                 emit = true;
                             }
                         }
-                        push_shadow(q, emit, S, LP, wt, c.pixel);
+                        push_shadow(q, emit, S, LP, wt, c.pixel, emit ? shadow_target(L, l, S, LP) : 0u);
                     }
                     {
                         uint32_t dim = WAPT_DIM_VPROBE + 2u * (uint32_t)(s * sc.n_lights + l);
@@ -555,16 +567,54 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KP
     }
 }
 
+// Adds the colours of the lanes with `pred` to their pixels' sums.  The red, green and blue of one pixel
+// go out from three neighbouring lanes: float atomics are carried out at the memory side, one request per
+// 64-byte segment that a wave instruction touches, so this takes one request per pixel where one atomic
+// instruction per channel takes three.  `stage` is 64 float4 of LDS owned by the calling wave; all lanes
+// of the wave call this together.
+__device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pred, uint32_t pixel, V3 c) {
+    unsigned long long m = __ballot(pred);
+    if (m == 0ull) return;
+    uint32_t lane = lane_id();
+    if (pred) stage[__popcll(m & ((1ull << lane) - 1ull))] = make_float4(c.x, c.y, c.z, u2f(pixel));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t n3 = 3u * (uint32_t)__popcll(m);
+    const float* sf = (const float*)stage;
+    for (uint32_t idx = lane; idx < n3; idx += 64u) {
+        uint32_t e = (idx * 43691u) >> 17;  // idx / 3 for idx < 192
+        uint32_t ch = idx - 3u * e;
+        float v = sf[4u * e + ch];
+        uint32_t px = f2u(sf[4u * e + 3u]);
+        if (v != 0.f) unsafeAtomicAdd(sum + (size_t)px * 3 + ch, v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // visibility() (cpp:693-790): walk from A to B through every surface in between.  Lanes stream
 // tasks like k_trace; a walk that has to continue past a transparent surface keeps its lane.
+//
+// Most walks end in one of three ways that need no second look at the scene, and those are decided
+// from what the search left in registers: (1) the search met an opaque surface clearly before B and
+// stopped there: zero visibility (cpp:778); (2) nothing was hit up to B while the walk is in the clear
+// global medium: full visibility of what is left (cpp:764-772); (3) same medium, and the only hit is
+// the quad of the light that B was sampled on, reached steeply: B lies on that quad, so the hit is B
+// itself to within a fraction of TRACE_BIAS, the walk arrives (cpp:775) and a plain (opaque, clear,
+// non-dielectric) surface changes nothing there.  Everything else - media, transparent surfaces, hits
+// within the search margin of B - takes the general path below, which follows the reference step by step.
 template <bool COUNT>
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
+    __shared__ float4 s_stage[WAPT_BLOCK];
+    float4* stage = &s_stage[threadIdx.x & ~63u];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = min(q.cnt[CNT_S], q.capS);
     TraceCount tc = {};
     uint32_t rays = 0;
     const int global_m = sc.n_objects;
+    const bool gclear = (sc.mats[global_m].flags & WAPT_MAT_CLEAR) != 0u;
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED + 32 * WAPT_FEED_STRIDE);
     Trav t = {};
     bool have_task = false, have_ray = false;
@@ -574,7 +624,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
     V3 V = v3(1, 1, 1);
     float ABl = 0.f, d = 0.f;
     int cur = global_m, it = 0;
-    uint32_t task = 0;
+    uint32_t task = 0, target = 0;
     for (;;) {
         uint32_t idx = feed.take(!have_task);
         if (idx != 0xffffffffu) {
@@ -589,6 +639,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             cur = global_m;
             it = 0;
             task = idx;
+            target = f2u(b.w);
             have_task = ABl > 0.f;
         }
         if (have_task && !have_ray) {
@@ -604,76 +655,93 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             rays++;
         }
         if (!__any(have_task)) break;
+        bool lit = false;
         if (trav_step<COUNT, true>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
             have_ray = false;
-            const V3 P0 = t.o, ABn = t.d;
-            float tmax = t.tmax;
-            uint32_t tri = t.hit;
-            if (tri != 0xffffffffu) {
-                // fp32 search distances are good to about 2e-5 relative; the walk's decisions compare the
-                // distance with |AB| +- 0.001, so a hit clearly beyond B needs no better value (B itself is
-                // used); one before or near B gets the fp64 distance (it may seed the next segment)
-                float dd32 = d + tmax;
-#ifndef WAPT_EXP_NO_REFINE
-                if (!(dd32 > ABl + (0.002f + 5e-5f * ABl))) tmax = refine_distance(sc.tm.tris, tri, P0, ABn, WAPT_TRACE_BIAS, tmax);
-#endif
-            }
-            V3 P1;
-            bool entering = false, opaque = false, blocked = false, lit = false;
-            int obj = -1;
-            float seg;   // |P1 - P0|
-            V3 hp = point_at(P0, tmax, ABn);
-            if (tri != 0xffffffffu) d += mag(hp - P0);
-            else d = 2.0f * ABl;
-            if (d <= ABl + WAPT_TRACE_BIAS) {
-                int prim;
-                V3 N = normalized(tri_normal(sc.tm.tris, tri, &obj, &prim));
-                const DMaterial& m = sc.mats[obj];
-                P1 = hp;
-                seg = mag(P1 - P0);
-                entering = dot(ABn, N) < 0.0f;
-                opaque = (m.flags & WAPT_MAT_OPAQUE) != 0u;
-                if (entering) {
-                    cur = global_m;
-                    // glass blocks shadow walks outright (cpp:757-759)
-                    blocked = (m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) && m.ior > 1.0f;
-                } else {
-                    cur = obj;
-                }
-            } else {
-                // the segment ends at B; on the first segment P0 is A and |B - A| is ABl itself
-                P1 = P0;
-                seg = ABl;
-                if (it > 0) {
-                    float4 b = q.SB[task];
-                    seg = mag(v3(b.x, b.y, b.z) - P0);
-                }
-                d = ABl;
-            }
+            const uint32_t tri = t.hit;
+            bool blocked = t.tblock < 0.f;  // (1)
+            bool general = false;
             if (!blocked) {
-                V = V * attenuation(sc.mats[cur], seg);
-                if (d >= ABl - WAPT_TRACE_BIAS) lit = true;
-                else if (opaque) blocked = true;
-                else if (V.x < WAPT_LOW_VIS && V.y < WAPT_LOW_VIS && V.z < WAPT_LOW_VIS) blocked = true;
-            }
-            if (!blocked && !lit && ++it >= 4096) blocked = true;
-            if (lit || blocked) {
-                if (lit) {
-                    float4 w4 = q.SC[task];
-                    uint32_t pixel = f2u(q.SA[task].w);
-                    DBG(pixel, "shadow task=%u lit V=%g w=%g d=%.6f ABl=%.6f\n", task, V.x, w4.x, d, ABl);
-#ifdef WAPT_EXP_NO_SHADOW_ATOMIC
-                    if (V.x < -1.f) add_rgb(q.sum, pixel, v3(w4.x, w4.y, w4.z) * V);
+                const bool in_clear = gclear && cur == global_m;
+                const bool at_target = tri != 0xffffffffu && target != 0u && (t.hflag & WAPT_TRI_PLAIN) &&
+                                       (t.hflag >> WAPT_TRI_OBJ_SHIFT) == target - 1u;
+#ifndef WAPT_EXP_NO_FAST_SHADOW
+                if (in_clear && (tri == 0xffffffffu || at_target)) lit = true;  // (2), (3)
+                else general = true;
 #else
-                    add_rgb(q.sum, pixel, v3(w4.x, w4.y, w4.z) * V);
+                general = true;
 #endif
-                }
-                have_task = false;
-            } else {
-                t.o = P1;
-                cur = entering ? obj : global_m;
             }
+            if (general) {
+                const V3 P0 = t.o, ABn = t.d;
+                float tmax = t.tmax;
+                if (tri != 0xffffffffu) {
+                    // fp32 search distances are good to about 2e-5 relative; the walk's decisions compare the
+                    // distance with |AB| +- 0.001, so a hit clearly beyond B needs no better value (B itself is
+                    // used); one before or near B gets the fp64 distance (it may seed the next segment)
+                    float dd32 = d + tmax;
+                    if (!(dd32 > ABl + (0.002f + 5e-5f * ABl))) tmax = refine_distance(sc.tm.tris, tri, P0, ABn, WAPT_TRACE_BIAS, tmax);
+                }
+                V3 P1;
+                bool entering = false, opaque = false;
+                int obj = -1;
+                float seg;   // |P1 - P0|
+                V3 hp = point_at(P0, tmax, ABn);
+                if (tri != 0xffffffffu) d += mag(hp - P0);
+                else d = 2.0f * ABl;
+                if (d <= ABl + WAPT_TRACE_BIAS) {
+                    int prim;
+                    V3 N = normalized(tri_normal(sc.tm.tris, tri, &obj, &prim));
+                    const DMaterial& m = sc.mats[obj];
+                    P1 = hp;
+                    seg = mag(P1 - P0);
+                    entering = dot(ABn, N) < 0.0f;
+                    opaque = (m.flags & WAPT_MAT_OPAQUE) != 0u;
+                    if (entering) {
+                        cur = global_m;
+                        // glass blocks shadow walks outright (cpp:757-759)
+                        blocked = (m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) && m.ior > 1.0f;
+                    } else {
+                        cur = obj;
+                    }
+                } else {
+                    // the segment ends at B; on the first segment P0 is A and |B - A| is ABl itself
+                    P1 = P0;
+                    seg = ABl;
+                    if (it > 0) {
+                        float4 b = q.SB[task];
+                        seg = mag(v3(b.x, b.y, b.z) - P0);
+                    }
+                    d = ABl;
+                }
+                if (!blocked) {
+                    V = V * attenuation(sc.mats[cur], seg);
+                    if (d >= ABl - WAPT_TRACE_BIAS) lit = true;
+                    else if (opaque) blocked = true;
+                    else if (V.x < WAPT_LOW_VIS && V.y < WAPT_LOW_VIS && V.z < WAPT_LOW_VIS) blocked = true;
+                }
+                if (!blocked && !lit && ++it >= 4096) blocked = true;
+                if (!lit && !blocked) {
+                    t.o = P1;
+                    cur = entering ? obj : global_m;
+                }
+            }
+            if (lit || blocked) have_task = false;
         }
+        // lanes whose walk has arrived add weight x visibility to their pixel
+        V3 contrib = v3(0, 0, 0);
+        uint32_t pixel = 0;
+        if (lit) {
+            float4 w4 = q.SC[task];
+            pixel = f2u(q.SA[task].w);
+            contrib = v3(w4.x, w4.y, w4.z) * V;
+            DBG(pixel, "shadow task=%u lit V=%g w=%g d=%.6f ABl=%.6f\n", task, V.x, w4.x, d, ABl);
+        }
+#ifdef WAPT_EXP_PLAIN_ATOMICS
+        if (lit) add_rgb(q.sum, pixel, contrib);
+#else
+        wave_add_rgb(q.sum, stage, lit, pixel, contrib);
+#endif
     }
     rays = wave_sum(rays);
     if (lane_id() == 0 && rays) atomicAdd(q.rays, (unsigned long long)rays);
@@ -969,6 +1037,16 @@ int validate_desc(const wapt_scene_desc* d) {
 
 }  // namespace
 
+// Flag byte of a triangle record (traverse.h) from the flags of its object's material.
+static uint32_t tri_flags_of(uint32_t mf) {
+    uint32_t f = 0;
+    if (mf & WAPT_MAT_OPAQUE) {
+        f |= WAPT_TRI_OPAQUE;
+        if ((mf & WAPT_MAT_CLEAR) && !(mf & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS))) f |= WAPT_TRI_PLAIN;
+    }
+    return f;
+}
+
 extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wapt_scene** out) {
     return wapt_scene_create_with(desc, device, WAPT_BUILDER_AUTO, out);
 }
@@ -1011,7 +1089,7 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     float blo[3], bhi[3];
     if (builder == WAPT_BUILDER_DEVICE_LBVH) {
         std::vector<uint8_t> opaque((size_t)desc->n_objects);
-        for (int i = 0; i < desc->n_objects; i++) opaque[i] = (desc->materials[i].flags & WAPT_MAT_OPAQUE) ? 1 : 0;
+        for (int i = 0; i < desc->n_objects; i++) opaque[i] = (uint8_t)tri_flags_of(desc->materials[i].flags);
         DeviceBvh8 db;
         std::string berr;
         if (!bvh8_build_device(desc->tri_verts, desc->tri_obj, desc->tri_prim, desc->n_tris, opaque.data(),
@@ -1040,8 +1118,8 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
         s->sah = bvh.sah_cost;
         memcpy(blo, bvh.lo, 12);
         memcpy(bhi, bvh.hi, 12);
-        // bit 0 of a triangle's last word: its object is opaque (lets shadow walks stop at the first such hit)
-        for (auto& T : bvh.tris) T.pad = (desc->materials[T.obj].flags & WAPT_MAT_OPAQUE) ? 1u : 0u;
+        // last word of a triangle record: what shadow walks need to know about its object without fetching the material
+        for (auto& T : bvh.tris) T.pad = tri_flags_of(desc->materials[T.obj].flags) | ((uint32_t)T.obj << WAPT_TRI_OBJ_SHIFT);
         HIPCHK_S(hipMalloc(&s->d_nodes, bvh.nodes.size() * sizeof(Bvh8Node)));
         HIPCHK_S(hipMalloc(&s->d_tris, bvh.tris.size() * sizeof(Bvh8Tri)));
         HIPCHK_S(hipMemcpy(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice));
@@ -1089,7 +1167,7 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     HIPCHK_S(hipGetDeviceProperties(&prop, device));
     uint32_t cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
     s->grid = cus * env_u32("WAPT_BLOCKS_PER_CU", 6);
-    s->sgrid = std::max(1u, cus * env_u32("WAPT_SBLOCKS_PER_CU", 2));  // 1024-thread blocks of the shading kernels
+    s->sgrid = std::max(1u, cus * env_u32("WAPT_SBLOCKS_PER_CU", 2) * (1024u / WAPT_SBLOCK));  // blocks of the shading kernels
     HIPCHK_S(hipMalloc((void**)&s->d_cnt, CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK_S(hipMemset(s->d_cnt, 0, CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK_S(hipMalloc((void**)&s->d_rays, 16 * sizeof(unsigned long long)));
