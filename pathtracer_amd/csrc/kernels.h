@@ -20,16 +20,21 @@
 #pragma once
 #include "traverse.h"
 
+// Counter words.  Every counter that kernels add to sits on a 256-byte line of its own: atomics on words of
+// one line queue behind each other like atomics on one word, and the shading kernels add to two or three
+// queue counters per step.
+#define WAPT_CNT_STRIDE 64
 enum {
-    CNT_QV = 3,   // segments of the current step that scatter (indices into the step)
-    CNT_S,        // shadow-walk tasks
-    CNT_P,        // probe tasks
-    CNT_OVERFLOW, // traversal-stack pushes dropped (must stay 0)
-    CNT_QOVERFLOW, // queue pushes dropped (must stay 0)
-    CNT_FEED = 128, // 3 x 32 work-feed counters of k_trace, k_shadow and k_probe, 64 words apart (zeroed by k_reset)
-    CNT_R0 = 8,   // CNT_R0 + d: tasks in R[d]
-    CNT_TOTAL = 128 + 3 * 32 * 64
+    CNT_OVERFLOW = 1 * WAPT_CNT_STRIDE,   // traversal-stack pushes dropped (must stay 0)
+    CNT_QOVERFLOW = 2 * WAPT_CNT_STRIDE,  // queue pushes dropped (must stay 0)
+    CNT_QV = 3 * WAPT_CNT_STRIDE,         // segments of the current step that scatter (indices into the step)
+    CNT_S = 4 * WAPT_CNT_STRIDE,          // shadow-walk tasks
+    CNT_P = 5 * WAPT_CNT_STRIDE,          // probe tasks
+    CNT_R0 = 8 * WAPT_CNT_STRIDE,         // CNT_R(d): tasks in R[d], d = 0..63
+    CNT_FEED = (8 + 64) * WAPT_CNT_STRIDE, // 3 x 32 work-feed counters of k_trace, k_shadow and k_probe (zeroed by k_reset)
+    CNT_TOTAL = CNT_FEED + 3 * 32 * 64
 };
+#define CNT_R(d) (CNT_R0 + (d) * WAPT_CNT_STRIDE)
 
 enum { RAY_CAMERA = 0, RAY_DIFFUSE = 1, RAY_SPECULAR = 2 };  // unidirectionalPathTracer.h:9-11
 

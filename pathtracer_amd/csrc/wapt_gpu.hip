@@ -21,18 +21,25 @@
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
+// Block size of the shading kernels.  Measured (surface kernel, ms per 64 spp of dragonChrome 1080p): 1024 threads
+// 14.9 (one block per CU: everything waits at its barriers), 768 threads at 6 waves per SIMD 12.9 (two blocks per
+// CU), 512 13.5, 256 19.7 (the smaller the block, the more atomics the queue counters take).
+#ifndef WAPT_SBLOCK
+#define WAPT_SBLOCK 768
+#endif
+#ifndef WAPT_SURFACE_WAVES
+#define WAPT_SURFACE_WAVES 6
+#endif
+
 // Queue compaction.  Lanes that have something to emit get consecutive slots: a ballot
 // and a population count give each lane its rank inside the wave, the waves' totals are
 // scanned by the block's first wave, and the block takes ONE atomic on the queue counter.
 // (One returning atomic per wave on a single counter tops out near 90 per microsecond on this
-// chip, far below what the streaming kernels need; one per 1024-thread block is 16x fewer.)
+// chip, far below what the streaming kernels need; one per block is 12x fewer.)
 // Every thread of the block must call this together.
-#ifndef WAPT_SBLOCK
-#define WAPT_SBLOCK 1024
-#endif
 __device__ __forceinline__ uint32_t block_push(uint32_t* counter, bool pred) {
-    __shared__ uint32_t s_cnt[WAPT_SBLOCK / 64];
-    __shared__ uint32_t s_off[WAPT_SBLOCK / 64];
+    __shared__ uint32_t s_cnt[16];
+    __shared__ uint32_t s_off[16];
     unsigned long long m = __ballot(pred);
     uint32_t lane = lane_id();
     uint32_t wave = threadIdx.x >> 6;
@@ -43,7 +50,7 @@ __device__ __forceinline__ uint32_t block_push(uint32_t* counter, bool pred) {
         uint32_t c = lane < nw ? s_cnt[lane] : 0u;
         uint32_t x = c;
 #pragma unroll
-        for (int o = 1; o < WAPT_SBLOCK / 64; o <<= 1) {
+        for (int o = 1; o < 16; o <<= 1) {
             uint32_t y = __shfl_up(x, o);
             if ((int)lane >= o) x += y;
         }
@@ -55,6 +62,43 @@ __device__ __forceinline__ uint32_t block_push(uint32_t* counter, bool pred) {
     }
     __syncthreads();
     return s_off[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// The same for up to three queues at once, with one pair of barriers: sixteen lanes of the first wave
+// scan each queue's wave totals side by side, and the three atomics leave in one instruction.
+// slot[k] is meaningful for lanes with pred[k].
+__device__ __forceinline__ void block_push3(uint32_t* const counter[3], const bool pred[3], uint32_t slot[3]) {
+    __shared__ uint32_t s_cnt3[3][16];
+    __shared__ uint32_t s_off3[3][16];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t nw = blockDim.x >> 6;
+    unsigned long long m[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        m[k] = __ballot(pred[k]);
+        if (lane == 0) s_cnt3[k][wave] = (uint32_t)__popcll(m[k]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t qi = lane >> 4, w = lane & 15u;
+        uint32_t c = (qi < 3u && w < nw) ? s_cnt3[qi][w] : 0u;
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t y = __shfl_up(x, o, 16);
+            if ((int)w >= o) x += y;
+        }
+        uint32_t total = __shfl(x, 15, 16);
+        uint32_t base = 0;
+        uint32_t* cp = qi == 0u ? counter[0] : (qi == 1u ? counter[1] : counter[2]);
+        if (w == 15u && qi < 3u && total) base = atomicAdd(cp, total);
+        base = __shfl(base, 15, 16);
+        if (qi < 3u && w < nw) s_off3[qi][w] = base + x - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; k++) slot[k] = s_off3[k][wave] + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull));
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -96,12 +140,9 @@ __device__ __forceinline__ bool finite_dir(V3 d) {
     return l > 0.25f && l < 4.0f;  // false for NaN
 }
 
-// Emits a radiance task of depth d+1 (all lanes of the wave call this together).
-__device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, bool pred, V3 o, V3 dir, V3 beta,
-                                              uint32_t pixel, uint32_t info, uint32_t key) {
-    pred = pred && finite_dir(dir);
-    uint32_t slot = block_push(&q.cnt[CNT_R0 + depth_next], pred);
-    if (!pred) return;
+// Stores a radiance task of depth d+1 in its slot (a slot beyond the queue is counted and dropped).
+__device__ __forceinline__ void write_radiance(const KQueues& q, int depth_next, uint32_t slot, V3 o, V3 dir, V3 beta,
+                                               uint32_t pixel, uint32_t info, uint32_t key) {
     if (slot >= q.capR) {
         atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
         return;
@@ -112,6 +153,14 @@ __device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, 
     q.RC[k] = make_float4(beta.x, beta.y, beta.z, u2f(key));
 }
 
+// Emits a radiance task of depth d+1 (all threads of the block call this together).
+__device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, bool pred, V3 o, V3 dir, V3 beta,
+                                              uint32_t pixel, uint32_t info, uint32_t key) {
+    pred = pred && finite_dir(dir);
+    uint32_t slot = block_push(&q.cnt[CNT_R(depth_next)], pred);
+    if (pred) write_radiance(q, depth_next, slot, o, dir, beta, pixel, info, key);
+}
+
 // `target`: 0, or 1 + the index of the area light whose quad `to` was sampled on when the walk arrives
 // at that quad steeply enough for its last hit to be decided without a second look (see k_shadow).
 __device__ __forceinline__ uint32_t shadow_target(const DLight& L, int l, V3 from, V3 to) {
@@ -120,10 +169,7 @@ __device__ __forceinline__ uint32_t shadow_target(const DLight& L, int l, V3 fro
     return fabsf(dot(wi, ld3(L.N))) >= 0.25f ? (uint32_t)l + 1u : 0u;
 }
 
-__device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from, V3 to, V3 w, uint32_t pixel, uint32_t target) {
-    pred = pred && !(w.x == 0.f && w.y == 0.f && w.z == 0.f);
-    uint32_t slot = block_push(&q.cnt[CNT_S], pred);
-    if (!pred) return;
+__device__ __forceinline__ void write_shadow(const KQueues& q, uint32_t slot, V3 from, V3 to, V3 w, uint32_t pixel, uint32_t target) {
     if (slot >= q.capS) {
         atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
         return;
@@ -133,11 +179,13 @@ __device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from
     q.SC[slot] = make_float4(w.x, w.y, w.z, 0.f);
 }
 
-__device__ __forceinline__ void push_probe(const KQueues& q, bool pred, V3 o, V3 dir, V3 w, uint32_t pixel,
-                                           uint32_t info, int medium) {
-    pred = pred && finite_dir(dir) && !(w.x == 0.f && w.y == 0.f && w.z == 0.f);
-    uint32_t slot = block_push(&q.cnt[CNT_P], pred);
-    if (!pred) return;
+__device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from, V3 to, V3 w, uint32_t pixel, uint32_t target) {
+    pred = pred && !is_zero(w);
+    uint32_t slot = block_push(&q.cnt[CNT_S], pred);
+    if (pred) write_shadow(q, slot, from, to, w, pixel, target);
+}
+
+__device__ __forceinline__ void write_probe(const KQueues& q, uint32_t slot, V3 o, V3 dir, V3 w, uint32_t pixel, uint32_t info, int medium) {
     if (slot >= q.capP) {
         atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
         return;
@@ -145,6 +193,13 @@ __device__ __forceinline__ void push_probe(const KQueues& q, bool pred, V3 o, V3
     q.PA[slot] = make_float4(o.x, o.y, o.z, u2f(pixel));
     q.PB[slot] = make_float4(dir.x, dir.y, dir.z, u2f(info));
     q.PC[slot] = make_float4(w.x, w.y, w.z, u2f((uint32_t)(medium + 1)));
+}
+
+__device__ __forceinline__ void push_probe(const KQueues& q, bool pred, V3 o, V3 dir, V3 w, uint32_t pixel,
+                                           uint32_t info, int medium) {
+    pred = pred && finite_dir(dir) && !is_zero(w);
+    uint32_t slot = block_push(&q.cnt[CNT_P], pred);
+    if (pred) write_probe(q, slot, o, dir, w, pixel, info, medium);
 }
 
 // One task of the current step together with its closest hit.
@@ -217,7 +272,7 @@ __device__ __forceinline__ V3 surface_weight(const KScene& sc, const HitCtx& c) 
 
 __global__ void k_reset(uint32_t* cnt, int r_slot, uint32_t r_value) {
     uint32_t t = threadIdx.x;
-    if (t <= CNT_P) cnt[t] = 0u;
+    if (t == 0) cnt[CNT_QV] = cnt[CNT_S] = cnt[CNT_P] = 0u;
     cnt[CNT_FEED + t * WAPT_FEED_STRIDE] = 0u;  // 96 threads, 96 feed counters (three traversal kernels per step)
     if (r_slot >= 0 && t == 0) cnt[r_slot] = r_value;
 }
@@ -306,7 +361,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene s
 // The kernel moves 48 B of task, 8 B of hit and 48 B of triangle in and 48 B per child or shadow task
 // out and is bound by that traffic, not by arithmetic: the materials share one kernel (lanes of a wave
 // may run different branches) so that nothing is read twice.
-__global__ __launch_bounds__(WAPT_SBLOCK) void k_surface(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
+__global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
     enum { NONE, LAMBERT, MIRROR, DIELECTRIC };
     GRID_LOOP(i, n) {
         const bool valid = i < n;
@@ -1166,7 +1221,7 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     hipDeviceProp_t prop;
     HIPCHK_S(hipGetDeviceProperties(&prop, device));
     uint32_t cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
-    s->grid = cus * env_u32("WAPT_BLOCKS_PER_CU", 6);
+    s->grid = cus * env_u32("WAPT_BLOCKS_PER_CU", 8);
     s->sgrid = std::max(1u, cus * env_u32("WAPT_SBLOCKS_PER_CU", 2) * (1024u / WAPT_SBLOCK));  // blocks of the shading kernels
     HIPCHK_S(hipMalloc((void**)&s->d_cnt, CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK_S(hipMemset(s->d_cnt, 0, CNT_TOTAL * sizeof(uint32_t)));
@@ -1483,7 +1538,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         uint32_t n = std::min(have[d], chunk_for(d));
         uint32_t start = have[d] - n;
         have[d] = start;
-        hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, d < td ? CNT_R0 + d + 1 : -1, 0u);
+        hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, d < td ? CNT_R(d + 1) : -1, 0u);
         tm.run(FAM_TRACE, [&] {
             if (prm->profile & 2) hipLaunchKernelGGL(k_trace<true>, grid, block, 0, st, ks, q, d, start, n);
             else hipLaunchKernelGGL(k_trace<false>, grid, block, 0, st, ks, q, d, start, n);
@@ -1505,7 +1560,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         if (d < td) {
             HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            have[d + 1] = std::min(s->h_cnt[CNT_R0 + d + 1], s->capR);
+            have[d + 1] = std::min(s->h_cnt[CNT_R(d + 1)], s->capR);
         }
     }
     unsigned long long h_rays[16] = {0};
