@@ -568,6 +568,19 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KP
             V3 cs = (rpdf_x * rrms * WAPT_PHASE) * (c.beta * vexp(v3(-st.x * x, -st.y * x, -st.z * x)) * ss);
             if (!act) cs = v3(0, 0, 0);
             float rls = 1.0f / (float)p.lsamples;
+            // (iii) indirect: one uniform direction, no emission at the next hit (cpp:587-609).  The task is
+            // emitted together with the first light's open-air tasks (one compaction for three queues).
+            V3 cdir;
+            bool cemit = act && doVol && (depth + 1 <= p.td);
+            {
+                uint32_t dim = WAPT_DIM_VCHILD + 2u * (uint32_t)s;
+                cdir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
+                cemit = cemit && finite_dir(cdir);
+            }
+            const V3 cbeta = ((4.0f * WAPT_PI) / pV) * cs;
+            const uint32_t cinfo = make_info(depth + 1, false, RAY_CAMERA, medium);
+            const uint32_t ckey = wapt_key_child(c.key, WAPT_SLOT_VOL | (uint32_t)s);
+            bool child_done = false;  // (uniform over the block: set under block-wide votes only)
             for (int l = 0; l < sc.n_lights; l++) {
                 const DLight& L = sc.lights[l];
                 if (__syncthreads_or(act && !inside)) {
@@ -584,40 +597,55 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KP
                                 float mis = pdf / (pdf + WAPT_MIS_CONST);
                                 if (rpdf == 0.0f) mis = 1.0f;
                                 wt = (rpdf * mis * rls) * (cs * ld3(L.Li));
-                                emit = true;
+                                emit = !is_zero(wt);
                             }
                         }
-                        push_shadow(q, emit, S, LP, wt, c.pixel, emit ? shadow_target(L, l, S, LP) : 0u);
-                    }
-                    {
+                        const uint32_t tgt = emit ? shadow_target(L, l, S, LP) : 0u;
+                        if (k > 0) {
+                            push_shadow(q, emit, S, LP, wt, c.pixel, tgt);
+                            continue;
+                        }
+                        // first light sample, the sphere-sampling probe and (with the first light) the child
                         uint32_t dim = WAPT_DIM_VPROBE + 2u * (uint32_t)(s * sc.n_lights + l);
-                        V3 dir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
-                        push_probe(q, act && !inside, S, dir, (4.0f * WAPT_PI) * cs, c.pixel, (uint32_t)l, medium);
+                        const V3 pdir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
+                        const V3 pw = (4.0f * WAPT_PI) * cs;
+                        uint32_t* const counters[3] = {&q.cnt[CNT_S], &q.cnt[CNT_P], &q.cnt[CNT_R(depth + 1)]};
+                        const bool preds[3] = {emit, act && !inside && finite_dir(pdir) && !is_zero(pw), cemit && !child_done};
+                        uint32_t slots[3];
+                        block_push3(counters, preds, slots);
+                        if (preds[0]) write_shadow(q, slots[0], S, LP, wt, c.pixel, tgt);
+                        if (preds[1]) write_probe(q, slots[1], S, pdir, pw, c.pixel, (uint32_t)l, medium);
+                        if (preds[2]) write_radiance(q, depth + 1, slots[2], S, cdir, cbeta, c.pixel, cinfo, ckey);
+                        child_done = true;
                     }
                 }
                 if (__syncthreads_or(act && inside_ok)) {
-                    // (ii) inside an object: 16 refracted connections per light (cpp:560-583)
+                    // (ii) inside an object: 16 refracted connections per light (cpp:560-583), three per compaction
                     V3 toL = normalized(ld3(L.centre) - S);
-                    for (int k = 0; k < 16; k++) {
-                        uint32_t dim = WAPT_DIM_VSINGLE + 2u * (uint32_t)((s * sc.n_lights + l) * 16 + k);
-                        float rpdf = 0.f;
-                        V3 dir = v3(0, 0, 1);
-                        if (act && inside_ok)
-                            dir = sphere_biased3(toL, 1.5f, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &rpdf);
-                        push_probe(q, act && inside_ok, S, dir, ((1.0f / 16.0f) * rpdf) * cs, c.pixel,
-                                   (uint32_t)l | (1u << 16), medium);
+                    for (int k0 = 0; k0 < 16; k0 += 3) {
+                        V3 dir[3], pw[3];
+                        bool preds[3];
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            const int k = k0 + j;
+                            uint32_t dim = WAPT_DIM_VSINGLE + 2u * (uint32_t)((s * sc.n_lights + l) * 16 + k);
+                            float rpdf = 0.f;
+                            dir[j] = v3(0, 0, 1);
+                            if (act && inside_ok && k < 16)
+                                dir[j] = sphere_biased3(toL, 1.5f, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &rpdf);
+                            pw[j] = ((1.0f / 16.0f) * rpdf) * cs;
+                            preds[j] = act && inside_ok && k < 16 && finite_dir(dir[j]) && !is_zero(pw[j]);
+                        }
+                        uint32_t* const counters[3] = {&q.cnt[CNT_P], &q.cnt[CNT_P], &q.cnt[CNT_P]};
+                        uint32_t slots[3];
+                        block_push3(counters, preds, slots);
+#pragma unroll
+                        for (int j = 0; j < 3; j++)
+                            if (preds[j]) write_probe(q, slots[j], S, dir[j], pw[j], c.pixel, (uint32_t)l | (1u << 16), medium);
                     }
                 }
             }
-            // (iii) indirect: one uniform direction, no emission at the next hit (cpp:587-609)
-            {
-                bool emit = act && doVol && (depth + 1 <= p.td);
-                uint32_t dim = WAPT_DIM_VCHILD + 2u * (uint32_t)s;
-                V3 dir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
-                push_radiance(q, depth + 1, emit, S, dir, ((4.0f * WAPT_PI) / pV) * cs, c.pixel,
-                              make_info(depth + 1, false, RAY_CAMERA, medium),
-                              wapt_key_child(c.key, WAPT_SLOT_VOL | (uint32_t)s));
-            }
+            if (!child_done) push_radiance(q, depth + 1, cemit, S, cdir, cbeta, c.pixel, cinfo, ckey);
         }
     }
 }
@@ -1309,10 +1337,12 @@ int ensure_spill(wapt_scene* s) {
 // is 2^26 tasks per depth (3 GiB per depth) and 2^29 shadow / probe tasks (24 GiB each) for scenes with
 // media, whose chunks are sized by the worst-case fan-out of a marched segment; all of it is cut down to
 // what the call can use and to a quarter of the free device memory.
-int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t shadows_per_task, uint64_t probes_per_task) {
+int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task, uint64_t shadows_per_task, uint64_t probes_per_task) {
     int depths = td + 1;
     uint32_t capR = env_u32("WAPT_RAD_CAP", 1u << 26);
-    capR = (uint32_t)std::min<uint64_t>(capR, (paths + 4095) & ~(uint64_t)4095);
+    // (a marched segment emits one child per march sample: the deeper queues of a scene with media fill up
+    //  from far fewer paths than they have slots)
+    capR = (uint32_t)std::min<uint64_t>(capR, ((paths + 4095) & ~(uint64_t)4095) * std::max<uint64_t>(kids_per_task, 1));
     capR = std::max(capR, 64u * 64u);
     capR &= ~63u;
     uint32_t capS = env_u32("WAPT_SHADOW_CAP", s->has_scatter ? (1u << 29) : capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
@@ -1445,7 +1475,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         uint64_t r0 = s->has_scatter ? (uint64_t)((double)s->max_segment * prm->mr) + 1 : 0;
         uint64_t sh = (uint64_t)s->n_lights * prm->lsamples * (1 + r0);
         uint64_t pr = r0 * (uint64_t)s->n_lights * (s->has_inside ? 16 : 1);
-        int rc = ensure_queues(s, prm->max_depth, n_paths, sh, pr);
+        int rc = ensure_queues(s, prm->max_depth, n_paths, (uint64_t)std::max(prm->hsamples, 1) + r0, sh, pr);
         if (rc) return rc;
     }
     KScene ks = s->ks;  // (after ensure_queues: it sets the spill area and stack capacity of ks.tm)
