@@ -58,7 +58,12 @@ __device__ __forceinline__ uint32_t hit4(uint32_t nlx, uint32_t nly, uint32_t nl
                                          uint32_t nhz, uint32_t meta4, float ax, float ay, float az, float ox,
                                          float oy, float oz, float tmin, float tmax, uint32_t octinv4) {
     uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-    uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+    // bits 0-2 in the bytes of inner children (the octant has three bits).  Two shift-ors: written as one
+    // expression the compiler turns them into a multiply by 7, which runs at quarter rate.
+    uint32_t inner1 = is_inner4 >> 4;
+    uint32_t inner_mask4 = inner1 | (inner1 << 1);
+    asm volatile("" : "+v"(inner_mask4));
+    inner_mask4 |= inner1 << 2;
     uint32_t bit_index4 = (meta4 ^ (octinv4 & inner_mask4)) & 0x1f1f1f1fu;
     uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
     uint32_t mask = 0;
@@ -191,7 +196,7 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
         uint32_t slot = (bit - 24u) ^ t.octinv;
         uint32_t rel = __popc(hits_imask & 0xffu & ((1u << slot) - 1u));
         uint32_t ni = t.G.x + rel;
-        const uint4* np = m.nodes + (size_t)ni * 5;
+        const uint4* np = m.nodes + (uint32_t)(ni * 5u);  // (32-bit index arithmetic: a 64-bit multiply runs at quarter rate)
         uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
         if (COUNT) cnt.nodes++;
 
@@ -208,7 +213,8 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
         uint32_t hy0 = ny ? n2.z : n4.x, hy1 = ny ? n2.w : n4.y;
         uint32_t lz0 = nz ? n4.z : n3.x, lz1 = nz ? n4.w : n3.y;
         uint32_t hz0 = nz ? n3.x : n4.z, hz1 = nz ? n3.y : n4.w;
-        const uint32_t octinv4 = t.octinv * 0x01010101u;
+        uint32_t octinv4 = t.octinv | (t.octinv << 8);  // the octant in all four bytes
+        octinv4 |= octinv4 << 16;
         uint32_t hm = hit4(lx0, ly0, lz0, hx0, hy0, hz0, n1.z, ax, ay, az, ox, oy, oz, t.tmin, t.tmax, octinv4);
         hm |= hit4(lx1, ly1, lz1, hx1, hy1, hz1, n1.w, ax, ay, az, ox, oy, oz, t.tmin, t.tmax, octinv4);
         t.G = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
@@ -231,7 +237,7 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
             uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
             bits &= bits - 1u;
             uint32_t ti = t.T.x + k;
-            const float4* tp = m.tris + (size_t)ti * 3;
+            const float4* tp = m.tris + (uint32_t)(ti * 3u);
             float4 a = tp[0], b = tp[1], c = tp[2];
             // (the flag word is only looked at for accepted hits: without this the compiler moves its load
             //  into that branch, where a whole memory round trip is then waited for with most lanes idle)

@@ -1333,13 +1333,14 @@ int ensure_spill(wapt_scene* s) {
 // (Re)allocates the work queues for a trace depth and a call that issues `paths` top-level tasks.
 // Capacities: large launches matter more than anything else for the traversal kernels (a launch ends
 // with a tail in which most lanes have run out of work: at 2^22 tasks per launch the lanes of the
-// closest-hit kernel were busy 55 % of the time, at 2^26 90 %), and HBM is plentiful, so the default
-// is 2^26 tasks per depth (3 GiB per depth) and 2^29 shadow / probe tasks (24 GiB each) for scenes with
-// media, whose chunks are sized by the worst-case fan-out of a marched segment; all of it is cut down to
-// what the call can use and to a quarter of the free device memory.
+// closest-hit kernel were busy 55 % of the time, at 2^26 90 %; whole frame, dragonChrome 1080p: 2^26 2931,
+// 2^27 3023, 2^28 3055 Mpaths/s), and HBM is plentiful, so the default is 2^28 tasks per depth (12 GiB per
+// depth) and 2^29 shadow / probe tasks (24 GiB each) for scenes with media, whose chunks are sized by the
+// worst-case fan-out of a marched segment; all of it is cut down to what the call can use and to a quarter
+// of the free device memory.
 int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task, uint64_t shadows_per_task, uint64_t probes_per_task) {
     int depths = td + 1;
-    uint32_t capR = env_u32("WAPT_RAD_CAP", 1u << 26);
+    uint32_t capR = env_u32("WAPT_RAD_CAP", 1u << 28);
     // (a marched segment emits one child per march sample: the deeper queues of a scene with media fill up
     //  from far fewer paths than they have slots)
     capR = (uint32_t)std::min<uint64_t>(capR, ((paths + 4095) & ~(uint64_t)4095) * std::max<uint64_t>(kids_per_task, 1));
