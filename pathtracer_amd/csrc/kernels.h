@@ -30,6 +30,7 @@ enum {
     CNT_QV = 3 * WAPT_CNT_STRIDE,         // segments of the current step that scatter (indices into the step)
     CNT_S = 4 * WAPT_CNT_STRIDE,          // shadow-walk tasks
     CNT_P = 5 * WAPT_CNT_STRIDE,          // probe tasks
+    CNT_QM = 6 * WAPT_CNT_STRIDE,         // march samples of the current step ((task, sample) pairs)
     CNT_R0 = 8 * WAPT_CNT_STRIDE,         // CNT_R(d): tasks in R[d], d = 0..63
     CNT_FEED = (8 + 64) * WAPT_CNT_STRIDE, // 3 x 32 work-feed counters of k_trace, k_shadow and k_probe (zeroed by k_reset)
     CNT_TOTAL = CNT_FEED + 3 * 32 * 64
@@ -53,6 +54,8 @@ struct KQueues {
     float4 *PA, *PB, *PC;
     uint2* hits;             // (t bits, triangle) per task of the current step
     uint32_t* QV;            // tasks of the current step whose segment is marched (scenes with media)
+    uint2* QM;               // their march samples: (task of the step, sample number)
+    uint32_t capQM;
     uint32_t capR, capS, capP;
     uint32_t* cnt;           // CNT_*
     unsigned long long* rays;  // closest-hit queries issued by shadow and probe kernels

@@ -272,7 +272,7 @@ __device__ __forceinline__ V3 surface_weight(const KScene& sc, const HitCtx& c) 
 
 __global__ void k_reset(uint32_t* cnt, int r_slot, uint32_t r_value) {
     uint32_t t = threadIdx.x;
-    if (t == 0) cnt[CNT_QV] = cnt[CNT_S] = cnt[CNT_P] = 0u;
+    if (t == 0) cnt[CNT_QV] = cnt[CNT_QM] = cnt[CNT_S] = cnt[CNT_P] = 0u;
     cnt[CNT_FEED + t * WAPT_FEED_STRIDE] = 0u;  // 96 threads, 96 feed counters (three traversal kernels per step)
     if (r_slot >= 0 && t == 0) cnt[r_slot] = r_value;
 }
@@ -496,61 +496,128 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
     }
 }
 
-// volumeScattering (cpp:429-621): ray march along the segment of one task
-__global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+// The segment of a task that volumeScattering() marches (cpp:221-230, 290, 429-457).
+struct Segment {
+    V3 A, IBn;
+    float len, pV;
+    bool doVol, inside;
+    int medium;
+    int rms;   // march samples (cpp:457), 0 for a degenerate segment
+};
+
+__device__ __forceinline__ Segment march_segment(const KScene& sc, const KParams& p, const HitCtx& c, int depth) {
+    Segment g;
+    g.A = c.o;
+    V3 B;
+    if (c.tri == 0xffffffffu) {
+        // exit point on the world sphere: the '+' root (cpp:226-227)
+        V3 rel = c.o - ld3(sc.wc);
+        float m = mag(rel);
+        float s1 = 0.f, s2 = 0.f;
+        solve_quadratic(1.0f, 2.0f * dot(rel, c.dir), m * m - sc.wr * sc.wr, &s1, &s2);
+        B = c.o + s1 * c.dir;
+        g.medium = -1;
+        g.inside = false;
+        g.doVol = true;
+        g.pV = 1.0f;
+    } else {
+        B = c.P;
+        g.medium = info_medium(c.info);
+        g.inside = !c.entering;  // objID != -1 (cpp:240-248)
+        g.pV = p_volume(depth);
+        g.doVol = wapt_rand(c.stream, WAPT_DIM_VOL) < g.pV;
+    }
+    V3 IB = B - g.A;
+    g.len = mag(IB);
+    g.IBn = (1.0f / g.len) * IB;
+    g.rms = (int)(g.len * p.mr / ((float)depth + 1.0f)) + 1;  // cpp:457
+    if (!(g.len > 0.f)) g.rms = 0;
+    return g;
+}
+
+// Slots for `count` consecutive entries per thread (a wave-wide prefix sum of the counts, then as block_push).
+__device__ __forceinline__ uint32_t block_push_count(uint32_t* counter, uint32_t count) {
+    __shared__ uint32_t s_cntN[16];
+    __shared__ uint32_t s_offN[16];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t nw = blockDim.x >> 6;
+    uint32_t x = count;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if ((int)lane >= o) x += y;
+    }
+    if (lane == 63u) s_cntN[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t c = lane < nw ? s_cntN[lane] : 0u;
+        uint32_t t = c;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t y = __shfl_up(t, o);
+            if ((int)lane >= o) t += y;
+        }
+        uint32_t total = __shfl(t, (int)nw - 1);
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(counter, total);
+        base = __shfl(base, 0);
+        if (lane < nw) s_offN[lane] = base + t - c;
+    }
+    __syncthreads();
+    return s_offN[wave] + x - count;
+}
+
+// One entry (task, sample) per march sample of the step's marched segments: the march kernel then has one
+// sample per lane, whatever the lengths of the segments (marching a whole segment per lane left most lanes
+// idle: a block ran until its longest segment was done).
+__global__ __launch_bounds__(WAPT_SBLOCK) void k_expand(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
     uint32_t n = q.cnt[CNT_QV];
     GRID_LOOP(j, n) {
-        bool valid = j < n;
-        HitCtx c = {};
-        V3 A = v3(0, 0, 0), IBn = v3(0, 0, 1);
-        float len = 0.f, pV = 1.f;
-        bool doVol = false, inside = false;
-        int medium = -1;
-        int rms = 0;
-        if (valid) {
-            uint32_t i = q.QV[j];
+        uint32_t i = 0, rms = 0;
+        if (j < n) {
+            i = q.QV[j];
+            HitCtx c = {};
             load_task(q, depth, start, i, c);
             load_hit(sc, q, i, c);
-            A = c.o;
-            V3 B;
-            if (c.tri == 0xffffffffu) {
-                // exit point on the world sphere: the '+' root (cpp:226-227)
-                V3 rel = c.o - ld3(sc.wc);
-                float m = mag(rel);
-                float s1 = 0.f, s2 = 0.f;
-                solve_quadratic(1.0f, 2.0f * dot(rel, c.dir), m * m - sc.wr * sc.wr, &s1, &s2);
-                B = c.o + s1 * c.dir;
-                medium = -1;
-                doVol = true;
-                pV = 1.0f;
-            } else {
-                B = c.P;
-                medium = info_medium(c.info);
-                inside = !c.entering;  // objID != -1 (cpp:240-248)
-                pV = p_volume(depth);
-                doVol = wapt_rand(c.stream, WAPT_DIM_VOL) < pV;
-            }
-            V3 IB = B - A;
-            len = mag(IB);
-            IBn = (1.0f / len) * IB;
-            rms = (int)(len * p.mr / ((float)depth + 1.0f)) + 1;  // cpp:457
-            if (!(len > 0.f)) rms = 0;
+            rms = (uint32_t)march_segment(sc, p, c, depth).rms;
         }
+        uint32_t base = block_push_count(&q.cnt[CNT_QM], rms);
+        for (uint32_t s = 0; s < rms; s++) {
+            if (base + s < q.capQM) q.QM[base + s] = make_uint2(i, s);
+            else atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
+        }
+    }
+}
+
+// volumeScattering (cpp:429-621): one march sample of the segment of one task per lane
+__global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+    uint32_t n = min(q.cnt[CNT_QM], q.capQM);
+    GRID_LOOP(j, n) {
+        const bool act = j < n;
+        HitCtx c = {};
+        Segment g = {};
+        g.IBn = v3(0, 0, 1);
+        g.pV = 1.f;
+        g.medium = -1;
+        int s = 0;
+        if (act) {
+            uint2 e = q.QM[j];
+            s = (int)e.y;
+            load_task(q, depth, start, e.x, c);
+            load_hit(sc, q, e.x, c);
+            g = march_segment(sc, p, c, depth);
+        }
+        const V3 A = g.A, IBn = g.IBn;
+        const float len = g.len, pV = g.pV;
+        const bool doVol = g.doVol, inside = g.inside;
+        const int medium = g.medium, rms = g.rms;
         const DMaterial& M = medium_of(sc, medium);
         V3 ss = ld3(M.ss), st = ld3(M.st);
         // the inside branch looks for the medium's own surface; the global medium has none
         bool inside_ok = inside && medium >= 0;
-        // trip count of the march loop, uniform over the block (block_push needs every thread)
-        __shared__ int s_rms_max;
-        if (threadIdx.x == 0) s_rms_max = 0;
-        __syncthreads();
-        if (rms > 0) atomicMax(&s_rms_max, rms);
-        __syncthreads();
-        const int rms_max = s_rms_max;
-        __syncthreads();
         float rrms = rms > 0 ? 1.0f / (float)rms : 0.f;
-        for (int s = 0; s < rms_max; s++) {
-            bool act = valid && s < rms;
+        {
             float x = 0.f, rpdf_x = 0.f;
             if (act) {
                 float u = wapt_rand(c.stream, WAPT_DIM_MARCH + (uint32_t)s);
@@ -626,22 +693,22 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KP
                         V3 dir[3], pw[3];
                         bool preds[3];
 #pragma unroll
-                        for (int j = 0; j < 3; j++) {
-                            const int k = k0 + j;
+                        for (int u = 0; u < 3; u++) {
+                            const int k = k0 + u;
                             uint32_t dim = WAPT_DIM_VSINGLE + 2u * (uint32_t)((s * sc.n_lights + l) * 16 + k);
                             float rpdf = 0.f;
-                            dir[j] = v3(0, 0, 1);
+                            dir[u] = v3(0, 0, 1);
                             if (act && inside_ok && k < 16)
-                                dir[j] = sphere_biased3(toL, 1.5f, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &rpdf);
-                            pw[j] = ((1.0f / 16.0f) * rpdf) * cs;
-                            preds[j] = act && inside_ok && k < 16 && finite_dir(dir[j]) && !is_zero(pw[j]);
+                                dir[u] = sphere_biased3(toL, 1.5f, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &rpdf);
+                            pw[u] = ((1.0f / 16.0f) * rpdf) * cs;
+                            preds[u] = act && inside_ok && k < 16 && finite_dir(dir[u]) && !is_zero(pw[u]);
                         }
                         uint32_t* const counters[3] = {&q.cnt[CNT_P], &q.cnt[CNT_P], &q.cnt[CNT_P]};
                         uint32_t slots[3];
                         block_push3(counters, preds, slots);
 #pragma unroll
-                        for (int j = 0; j < 3; j++)
-                            if (preds[j]) write_probe(q, slots[j], S, dir[j], pw[j], c.pixel, (uint32_t)l | (1u << 16), medium);
+                        for (int u = 0; u < 3; u++)
+                            if (preds[u]) write_probe(q, slots[u], S, dir[u], pw[u], c.pixel, (uint32_t)l | (1u << 16), medium);
                     }
                 }
             }
@@ -663,13 +730,17 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t n3 = 3u * (uint32_t)__popcll(m);
+    const uint32_t n = (uint32_t)__popcll(m), n3 = 3u * n;
     const float* sf = (const float*)stage;
     for (uint32_t idx = lane; idx < n3; idx += 64u) {
         uint32_t e = (idx * 43691u) >> 17;  // idx / 3 for idx < 192
         uint32_t ch = idx - 3u * e;
-        float v = sf[4u * e + ch];
         uint32_t px = f2u(sf[4u * e + 3u]);
+        // neighbouring lanes that hold the same pixel (march samples of one segment sit next to each other
+        // in the queues) are summed here, and the first of the run adds the sum
+        if (e > 0u && f2u(sf[4u * e - 1u]) == px) continue;
+        float v = sf[4u * e + ch];
+        for (uint32_t k = e + 1u; k < n && f2u(sf[4u * k + 3u]) == px; k++) v += sf[4u * k + ch];
         if (v != 0.f) unsafeAtomicAdd(sum + (size_t)px * 3 + ch, v);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -846,6 +917,8 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
 // second ray.
 __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
+    __shared__ float4 s_stage[WAPT_BLOCK];
+    float4* astage = &s_stage[threadIdx.x & ~63u];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = min(q.cnt[CNT_P], q.capP);
     TraceCount tc = {};
@@ -867,6 +940,8 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
             rays++;
         }
         if (!__any(have_task)) break;
+        bool lit = false;
+        V3 contrib = v3(0, 0, 0);
         if (trav_step<false>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
             have_ray = false;
             have_task = false;
@@ -888,7 +963,8 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
                 if (stage == 1) {
                     if (obj == light) {
                         V3 att = attenuation(sc.mats[sc.n_objects], mag(hp - S)) * attenuation(M, seg0);
-                        add_rgb(q.sum, f2u(q.PA[task].w), (1.0f - F0) * (w * ld3(L.Li) * att));
+                        contrib = (1.0f - F0) * (w * ld3(L.Li) * att);
+                        lit = true;
                     }
                 } else if (kind == 0) {
                     if (obj == light) {
@@ -896,7 +972,8 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
                         float alt = light_pdf(L, hp, S);
                         float mis = WAPT_MIS_CONST / (WAPT_MIS_CONST + alt);
                         if (mis != mis) mis = 1.0f;
-                        add_rgb(q.sum, f2u(q.PA[task].w), mis * (w * ld3(L.Li) * att));
+                        contrib = mis * (w * ld3(L.Li) * att);
+                        lit = true;
                     }
                 } else if (obj == medium) {
                     V3 N = normalized(Ng);
@@ -914,6 +991,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
                 }
             }
         }
+        wave_add_rgb(q.sum, astage, lit, lit ? f2u(q.PA[task].w) : 0u, contrib);
     }
     rays = wave_sum(rays);
     if (lane_id() == 0 && rays) atomicAdd(q.rays, (unsigned long long)rays);
@@ -1348,18 +1426,27 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
     capR &= ~63u;
     uint32_t capS = env_u32("WAPT_SHADOW_CAP", s->has_scatter ? (1u << 29) : capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
     uint32_t capP = env_u32("WAPT_PROBE_CAP", s->has_scatter ? (1u << 29) : 64u);
-    if (s->has_scatter) {
-        // a call with few paths cannot fill more than its worst-case fan-out
-        auto need = [&](uint64_t per_task) { return std::max<uint64_t>(((paths + 4095) & ~(uint64_t)4095) * std::max<uint64_t>(per_task, 1), 1u << 16); };
-        capS = (uint32_t)std::min<uint64_t>(capS, need(shadows_per_task));
-        capP = (uint32_t)std::min<uint64_t>(capP, need(probes_per_task));
-    }
-    auto footprint = [&](uint64_t r, uint64_t sh, uint64_t pr) {
-        return (uint64_t)depths * r * 48 + sh * 48 + pr * 48 + r * 12;
-    };
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = (uint64_t)(free_b + s->queue_bytes) / 4;
+    const uint64_t budget = (uint64_t)(free_b + s->queue_bytes) / 4;
+    if (s->has_scatter) {
+        // A launch of c tasks of depth 0 needs c x kids slots in R[1], c x shadows in S and c x probes in P (and
+        // the deeper launches less): the budget goes to the queues in these proportions, which gives the largest
+        // launch the memory allows (one capacity for all three starves the probe queue of a scene whose rays march
+        // inside an object: 16 probes per light and march sample).
+        const uint64_t kids = std::max<uint64_t>(kids_per_task, 1), sh = std::max<uint64_t>(shadows_per_task, 1),
+                       pr = std::max<uint64_t>(probes_per_task, 1);
+        const uint64_t per_task = (uint64_t)depths * kids * 48 + sh * 48 + pr * 56 + 12 * kids;
+        uint64_t c = std::min<uint64_t>((paths + 4095) & ~(uint64_t)4095, budget / per_task);
+        c = std::max<uint64_t>(c, 4096);
+        auto cap32 = [](uint64_t v) { return (uint32_t)std::min<uint64_t>(v, 0xfffff000u); };
+        capR = std::min(capR, cap32(c * kids)) & ~63u;
+        capS = env_u32("WAPT_SHADOW_CAP", cap32(c * sh));
+        capP = env_u32("WAPT_PROBE_CAP", cap32(c * pr));
+    }
+    auto footprint = [&](uint64_t r, uint64_t sh, uint64_t pr) {
+        return (uint64_t)depths * r * 48 + sh * 48 + pr * 56 + r * 12;
+    };
     while (footprint(capR, capS, capP) > budget && (capR > (1u << 16) || capS > (1u << 20))) {
         if (capR > (1u << 16)) capR >>= 1;
         if (capS > (1u << 20)) capS >>= 1;
@@ -1387,6 +1474,9 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
     size_t oPA = take((size_t)capP * 16), oPB = take((size_t)capP * 16), oPC = take((size_t)capP * 16);
     size_t oH = take((size_t)capR * 8);
     size_t oQV = take(s->has_scatter ? (size_t)capR * 4 : 256);
+    // (task, sample) pairs of the march kernel: a task has no more march samples than probes
+    const uint32_t capQM = s->has_scatter ? capP : 32u;
+    size_t oQM = take((size_t)capQM * 8);
     HIPCHK(hipMalloc(&s->d_queue_block, bytes));
     char* b = (char*)s->d_queue_block;
     KQueues& q = s->kq;
@@ -1401,6 +1491,8 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
     q.PC = (float4*)(b + oPC);
     q.hits = (uint2*)(b + oH);
     q.QV = (uint32_t*)(b + oQV);
+    q.QM = (uint2*)(b + oQM);
+    q.capQM = capQM;
     q.capR = capR;
     q.capS = capS;
     q.capP = capP;
@@ -1527,6 +1619,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         if (d < td) c = std::min<uint64_t>(c, s->capR / kids);
         if (shadows) c = std::min<uint64_t>(c, s->capS / shadows);
         if (probes) c = std::min<uint64_t>(c, s->capP / probes);
+        if (r) c = std::min<uint64_t>(c, s->kq.capQM / r);
         return (uint32_t)c;
     };
     for (int d = 0; d <= td; d++)
@@ -1578,7 +1671,10 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         n_trace_launches++;
         tm.run(FAM_SHADE, [&] { hipLaunchKernelGGL(k_surface, sgrid, sblock, 0, st, ks, q, kp, d, start, n); });
         if (s->has_scatter) {
-            tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_volume, sgrid, sblock, 0, st, ks, q, kp, d, start); });
+            tm.run(FAM_VOLUME, [&] {
+                hipLaunchKernelGGL(k_expand, sgrid, sblock, 0, st, ks, q, kp, d, start);
+                hipLaunchKernelGGL(k_volume, sgrid, sblock, 0, st, ks, q, kp, d, start);
+            });
             tm.run(FAM_PROBE, [&] { hipLaunchKernelGGL(k_probe, grid, block, 0, st, ks, q); });
         }
         {
