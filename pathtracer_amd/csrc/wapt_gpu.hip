@@ -30,6 +30,16 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 #ifndef WAPT_SURFACE_WAVES
 #define WAPT_SURFACE_WAVES 6
 #endif
+// block size of the march kernel (115 registers: two blocks of 512 threads fit a CU, one of 768)
+#ifndef WAPT_VBLOCK
+#define WAPT_VBLOCK 512
+#endif
+#ifndef WAPT_VOLUME_WAVES
+#define WAPT_VOLUME_WAVES 4
+#endif
+#ifndef WAPT_PROBE_WAVES
+#define WAPT_PROBE_WAVES 7
+#endif
 
 // Queue compaction.  Lanes that have something to emit get consecutive slots: a ballot
 // and a population count give each lane its rank inside the wave, the waves' totals are
@@ -571,7 +581,7 @@ __device__ __forceinline__ uint32_t block_push_count(uint32_t* counter, uint32_t
 // One entry (task, sample) per march sample of the step's marched segments: the march kernel then has one
 // sample per lane, whatever the lengths of the segments (marching a whole segment per lane left most lanes
 // idle: a block ran until its longest segment was done).
-__global__ __launch_bounds__(WAPT_SBLOCK) void k_expand(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+__global__ __launch_bounds__(WAPT_VBLOCK) void k_expand(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
     uint32_t n = q.cnt[CNT_QV];
     GRID_LOOP(j, n) {
         uint32_t i = 0, rms = 0;
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_expand(KScene sc, KQueues q, KP
 }
 
 // volumeScattering (cpp:429-621): one march sample of the segment of one task per lane
-__global__ __launch_bounds__(WAPT_SBLOCK) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+__global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
     uint32_t n = min(q.cnt[CNT_QM], q.capQM);
     GRID_LOOP(j, n) {
         const bool act = j < n;
@@ -813,18 +823,14 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
         if (trav_step<COUNT, true>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
             have_ray = false;
             const uint32_t tri = t.hit;
-            bool blocked = t.tblock < 0.f;  // (1)
+            bool blocked = sc.fast_shadow && t.tblock < 0.f;  // (1)
             bool general = false;
             if (!blocked) {
                 const bool in_clear = gclear && cur == global_m;
                 const bool at_target = tri != 0xffffffffu && target != 0u && (t.hflag & WAPT_TRI_PLAIN) &&
                                        (t.hflag >> WAPT_TRI_OBJ_SHIFT) == target - 1u;
-#ifndef WAPT_EXP_NO_FAST_SHADOW
-                if (in_clear && (tri == 0xffffffffu || at_target)) lit = true;  // (2), (3)
+                if (sc.fast_shadow && in_clear && (tri == 0xffffffffu || at_target)) lit = true;  // (2), (3)
                 else general = true;
-#else
-                general = true;
-#endif
             }
             if (general) {
                 const V3 P0 = t.o, ABn = t.d;
@@ -891,11 +897,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             contrib = v3(w4.x, w4.y, w4.z) * V;
             DBG(pixel, "shadow task=%u lit V=%g w=%g d=%.6f ABl=%.6f\n", task, V.x, w4.x, d, ABl);
         }
-#ifdef WAPT_EXP_PLAIN_ATOMICS
-        if (lit) add_rgb(q.sum, pixel, contrib);
-#else
         wave_add_rgb(q.sum, stage, lit, pixel, contrib);
-#endif
     }
     rays = wave_sum(rays);
     if (lane_id() == 0 && rays) atomicAdd(q.rays, (unsigned long long)rays);
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
 // directLightHit (cpp:670-687) and directLightingSingleScatter (cpp:631-665).  Lanes stream tasks like
 // k_trace; a single-scatter probe that reaches its object's surface keeps its lane for the refracted
 // second ray.
-__global__ __launch_bounds__(WAPT_BLOCK) void k_probe(KScene sc, KQueues q) {
+__global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     __shared__ float4 s_stage[WAPT_BLOCK];
     float4* astage = &s_stage[threadIdx.x & ~63u];
@@ -1080,7 +1082,7 @@ struct wapt_scene {
     void* d_queue_block = nullptr;
     size_t queue_bytes = 0;
     int queue_depths = 0;
-    uint32_t grid = 0, sgrid = 0;
+    uint32_t grid = 0, sgrid = 0, cus = 1;
     uint32_t capR = 0, capS = 0, capP = 0;
     bool has_scatter = false, has_inside = false;
     float max_segment = 0.f;
@@ -1327,6 +1329,7 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     hipDeviceProp_t prop;
     HIPCHK_S(hipGetDeviceProperties(&prop, device));
     uint32_t cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
+    s->cus = cus;
     s->grid = cus * env_u32("WAPT_BLOCKS_PER_CU", 8);
     s->sgrid = std::max(1u, cus * env_u32("WAPT_SBLOCKS_PER_CU", 2) * (1024u / WAPT_SBLOCK));  // blocks of the shading kernels
     HIPCHK_S(hipMalloc((void**)&s->d_cnt, CNT_TOTAL * sizeof(uint32_t)));
@@ -1346,6 +1349,8 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     s->ks.lights = (const DLight*)s->d_lights;
     s->ks.n_lights = desc->n_lights;
     s->ks.n_objects = desc->n_objects;
+    // WAPT_GENERAL_SHADOW=1 sends every shadow walk through the step-by-step path (the tests compare the two)
+    s->ks.fast_shadow = env_u32("WAPT_GENERAL_SHADOW", 0) ? 0 : 1;
     s->ks.cam = to_device(desc->camera);
     s->camera = desc->camera;
     memcpy(s->ks.wc, desc->world_center, 12);
@@ -1603,6 +1608,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     hipStream_t st = s->stream;
     const dim3 grid(s->grid), block(WAPT_BLOCK);
     const dim3 sgrid(s->sgrid), sblock(WAPT_SBLOCK);
+    const dim3 vgrid(s->cus * env_u32("WAPT_VBLOCKS_PER_CU", 2048u / WAPT_VBLOCK)), vblock(WAPT_VBLOCK);
 
     // worst-case fan-out of one task of depth d (sizes the chunk taken from R[d])
     const int L = s->n_lights;
@@ -1672,8 +1678,8 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         tm.run(FAM_SHADE, [&] { hipLaunchKernelGGL(k_surface, sgrid, sblock, 0, st, ks, q, kp, d, start, n); });
         if (s->has_scatter) {
             tm.run(FAM_VOLUME, [&] {
-                hipLaunchKernelGGL(k_expand, sgrid, sblock, 0, st, ks, q, kp, d, start);
-                hipLaunchKernelGGL(k_volume, sgrid, sblock, 0, st, ks, q, kp, d, start);
+                hipLaunchKernelGGL(k_expand, vgrid, vblock, 0, st, ks, q, kp, d, start);
+                hipLaunchKernelGGL(k_volume, vgrid, vblock, 0, st, ks, q, kp, d, start);
             });
             tm.run(FAM_PROBE, [&] { hipLaunchKernelGGL(k_probe, grid, block, 0, st, ks, q); });
         }

@@ -183,3 +183,22 @@ def test_cli_renders_the_same_image_as_the_python_mirror(tmp_path):
     pb = np.frombuffer(b, np.uint8, offset=138).astype(int)
     # float atomics add in a different order from run to run: allow the last bit of a few pixels to differ
     assert a[:138] == b[:138] and np.abs(pa - pb).max() <= 1 and (pa != pb).mean() < 0.01
+
+
+@pytest.mark.parametrize("name", ["cornell_spheres", "dragon_chrome", "dragon_glass", "fog_area"])
+def test_shadow_walk_shortcuts_equal_the_general_path(name, monkeypatch):
+    """Shadow walks that the kernel finishes from registers (opaque surface before the end point, clear miss, hit on
+    the sampled light's own quad) against the same walks sent through the step-by-step path of visibility()
+    (WAPT_GENERAL_SHADOW=1, read at scene creation): same image up to the order of the float atomics, same number
+    of closest-hit queries."""
+    sc, spp, kw = {
+        "cornell_spheres": (scenes.cornell(res=(96, 96), spheres=True, sphere_segments=(16, 32)), 16, dict(hsamples=2, lsamples=2)),
+        "dragon_chrome": (scenes.dragon("chrome", res=(128, 72), n_along=200, n_around=60), 16, {}),
+        "dragon_glass": (scenes.dragon("glass", res=(64, 36), n_along=200, n_around=60, td=6), 16, {}),
+        "fog_area": (scenes.fog(res=(24, 16), lights="area"), 2, {}),
+    }[name]
+    fast, st_fast = gpu_render(sc, spp, seed=3, **kw)
+    monkeypatch.setenv("WAPT_GENERAL_SHADOW", "1")
+    general, st_gen = gpu_render(sc, spp, seed=3, **kw)
+    np.testing.assert_allclose(fast, general, rtol=2e-4, atol=1e-6)
+    assert st_fast.rays == st_gen.rays
