@@ -81,14 +81,17 @@ def fog(res=(1920, 1080), td=3, lights="sphere", spheres=True):
     return Scene(_cam(res), ls, mats, ms, global_medium=material("medium", **FOG), td=td, me=0.0, mr=0.01)
 
 
-def stress(res=(3840, 2160), copies=64, n_along=1320, n_around=330, td=3):
-    """BASELINE config 4: `copies` transformed dragons flattened into one soup, materials cycling."""
+def stress(res=(3840, 2160), copies=64, n_along=1320, n_around=330, td=3, materials="mixed"):
+    """BASELINE config 4: `copies` transformed dragons flattened into one soup, materials cycling
+    (materials="opaque": diffuse and mirror only, the traversal-bound variant used for the HBM traffic profile)."""
     mats, ms = _box()
     v, f = meshes.dragon_standin(n_along, n_around)
     centre = np.array([307.0, 0.0, 274.0])
     side = int(np.ceil(np.sqrt(copies)))
     kinds = [material("diffuse", (0.6, 0.6, 0.7)), material("specular", (1.0, 1.0, 1.0)),
              material("dielectric", ior=GLASS_IOR), material("dielectricsss", **MILK)]
+    if materials == "opaque":
+        kinds = kinds[:2]
     for k in range(copies):
         a = 2.0 * np.pi * (k * 0.61803398875 % 1.0)
         rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
@@ -96,5 +99,5 @@ def stress(res=(3840, 2160), copies=64, n_along=1320, n_around=330, td=3):
         off = np.array([(k % side + 0.5) * 550.0 / side, 0.0, (k // side + 0.5) * 550.0 / side])
         vv = ((v.astype(np.float64) - centre) * s) @ rot.T + off
         ms.append(meshes.expand(vv.astype(np.float32), f))
-        mats.append(kinds[k % 4])
+        mats.append(kinds[k % len(kinds)])
     return Scene(_cam(res), [area_light(**LIGHT)], mats, ms, td=td, me=0.0, mr=0.01)

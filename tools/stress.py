@@ -13,12 +13,13 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--builder", default="auto", choices=["auto", "host", "device"])
+    ap.add_argument("--materials", default="mixed", choices=["mixed", "opaque"])
     args = ap.parse_args()
     import torch
     from pathtracer_amd import renderer, scenes
     W, H = (int(x) for x in args.res.split("x"))
     t0 = time.time()
-    sc = scenes.stress(res=(W, H), copies=args.copies)
+    sc = scenes.stress(res=(W, H), copies=args.copies, materials=args.materials)
     t_mesh = time.time() - t0
     t0 = time.time()
     content = renderer.wa_content(sc, device=0, builder=args.builder)
@@ -35,7 +36,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.time() - t0) / args.steps
     img = (acc / (args.spp * args.steps)).cpu()
-    out = {"copies": args.copies, "triangles": int(info.n_tris), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.max_depth), "builder": int(info.builder), "build_s": round(float(info.build_seconds), 2), "sah": float(info.sah_cost),
+    out = {"copies": args.copies, "materials": args.materials, "triangles": int(info.n_tris), "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.max_depth), "builder": int(info.builder), "build_s": round(float(info.build_seconds), 2), "sah": float(info.sah_cost),
            "bvh_gb": (info.node_bytes + info.tri_bytes) / 1e9, "mesh_s": round(t_mesh, 1), "scene_create_s": round(t_build, 1),
            "res": args.res, "spp": args.spp, "seconds": dt, "mpaths_per_s": W * H * args.spp / dt / 1e6,
            "mrays_per_s": st.rays / dt / 1e6, "rays_per_path": st.rays / (W * H * args.spp), "stack_overflows": int(st.stack_overflows),
