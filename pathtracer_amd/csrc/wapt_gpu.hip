@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cfloat>
 #include <memory>
 #include <chrono>
 #include <cmath>
@@ -285,6 +286,13 @@ __global__ void k_reset(uint32_t* cnt, int r_slot, uint32_t r_value) {
     if (t == 0) cnt[CNT_QV] = cnt[CNT_QM] = cnt[CNT_S] = cnt[CNT_P] = 0u;
     cnt[CNT_FEED + t * WAPT_FEED_STRIDE] = 0u;  // 96 threads, 96 feed counters (three traversal kernels per step)
     if (r_slot >= 0 && t == 0) cnt[r_slot] = r_value;
+}
+
+// Between two slices of a step's march samples: the shadow and probe queues and the feeds of their kernels start over.
+__global__ void k_reset_sp(uint32_t* cnt) {
+    uint32_t t = threadIdx.x;
+    if (t == 0) cnt[CNT_S] = cnt[CNT_P] = 0u;
+    cnt[CNT_FEED + (32 + t) * WAPT_FEED_STRIDE] = 0u;  // 64 threads: feed counters of k_shadow and k_probe
 }
 
 // renderTile's sample loop + generateRayForPixel (cpp:122-132, fundamentals.cpp:306-327)
@@ -593,16 +601,13 @@ __global__ __launch_bounds__(WAPT_VBLOCK) void k_expand(KScene sc, KQueues q, KP
             rms = (uint32_t)march_segment(sc, p, c, depth).rms;
         }
         uint32_t base = block_push_count(&q.cnt[CNT_QM], rms);
-        for (uint32_t s = 0; s < rms; s++) {
-            if (base + s < q.capQM) q.QM[base + s] = make_uint2(i, s);
-            else atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
-        }
+        for (uint32_t s = 0; s < rms; s++)
+            if (base + s < q.capQM) q.QM[base + s] = make_uint2(i, s);  // (the host refuses the step if the count exceeds the list)
     }
 }
 
 // volumeScattering (cpp:429-621): one march sample of the segment of one task per lane
-__global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
-    uint32_t n = min(q.cnt[CNT_QM], q.capQM);
+__global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t m0, uint32_t n) {
     GRID_LOOP(j, n) {
         const bool act = j < n;
         HitCtx c = {};
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScen
         g.medium = -1;
         int s = 0;
         if (act) {
-            uint2 e = q.QM[j];
+            uint2 e = q.QM[m0 + j];
             s = (int)e.y;
             load_task(q, depth, start, e.x, c);
             load_hit(sc, q, e.x, c);
@@ -1085,7 +1090,9 @@ struct wapt_scene {
     uint32_t grid = 0, sgrid = 0, cus = 1;
     uint32_t capR = 0, capS = 0, capP = 0;
     bool has_scatter = false, has_inside = false;
-    float max_segment = 0.f;
+    float max_segment = 0.f;   // longest possible segment (everything lies in a ball around the world centre)
+    float max_inside = 0.f;    // longest box diagonal of an object whose inside scatters
+    bool global_scatters = false;
     int n_lights = 0;
     wapt_camera camera;  // as described by the caller (the progressive interface re-derives lower resolutions from it)
     std::vector<hipEvent_t> ev_pool;
@@ -1302,6 +1309,28 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
             if (i < desc->n_objects) s->has_inside = true;
         }
     }
+    s->global_scatters = mats[desc->n_objects].scatters != 0u;
+    if (s->has_inside) {
+        // box diagonal of every object with a scattering inside: a segment that lies inside a closed object is no
+        // longer (sizes the launches of scenes with media, see chunk_for)
+        std::vector<float> lo((size_t)desc->n_objects * 3, FLT_MAX), hi((size_t)desc->n_objects * 3, -FLT_MAX);
+        for (uint64_t t = 0; t < desc->n_tris; t++) {
+            const int o = desc->tri_obj[t];
+            if (!mats[o].scatters) continue;
+            const float* v = desc->tri_verts + 9 * t;
+            for (int k = 0; k < 9; k++) {
+                lo[(size_t)o * 3 + k % 3] = std::min(lo[(size_t)o * 3 + k % 3], v[k]);
+                hi[(size_t)o * 3 + k % 3] = std::max(hi[(size_t)o * 3 + k % 3], v[k]);
+            }
+        }
+        double dmax = 0.0;
+        for (int o = 0; o < desc->n_objects; o++) {
+            if (!mats[o].scatters || lo[(size_t)o * 3] > hi[(size_t)o * 3]) continue;
+            double dx = (double)hi[o * 3] - lo[o * 3], dy = (double)hi[o * 3 + 1] - lo[o * 3 + 1], dz = (double)hi[o * 3 + 2] - lo[o * 3 + 2];
+            dmax = std::max(dmax, std::sqrt(dx * dx + dy * dy + dz * dz));
+        }
+        s->max_inside = (float)(dmax * 1.001);
+    }
     HIPCHK_S(hipMalloc(&s->d_mats, mats.size() * sizeof(DMaterial)));
     HIPCHK_S(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
     std::vector<DLight> lights((size_t)std::max(desc->n_lights, 1));
@@ -1411,6 +1440,26 @@ int ensure_spill(wapt_scene* s) {
     s->ks.tm.spill_stride = lanes;
     s->ks.tm.stack_cap = WAPT_LDS_STACK + depth_slots;
     return WAPT_OK;
+}
+
+// What one task of depth d emits at most.  A task marches one segment: through the global medium (any length up to
+// max_segment; light sampling and one probe per light and march sample) or inside an object (closed objects: no longer
+// than the object's box diagonal; 16 probes per light and march sample).  A segment that lies inside an OPEN mesh can
+// exceed that bound: the render loop checks the exact number of march samples of a step before it emits anything
+// and refuses the step then.
+struct FanOut {
+    uint64_t marches, kids, shadows, probes;
+};
+FanOut fan_out(const wapt_scene* s, const wapt_render_params* prm, int d) {
+    FanOut f;
+    const uint64_t r_out = s->global_scatters ? (uint64_t)((double)s->max_segment * prm->mr / (d + 1.0)) + 1 : 0;
+    const uint64_t r_in = s->has_inside ? (uint64_t)((double)s->max_inside * prm->mr / (d + 1.0)) + 1 : 0;
+    const uint64_t L = (uint64_t)s->n_lights;
+    f.marches = std::max(r_out, r_in);
+    f.kids = (uint64_t)std::max(prm->hsamples, 1) + f.marches;
+    f.shadows = L * prm->lsamples * (1 + r_out);
+    f.probes = L * std::max(r_out, 16 * r_in);
+    return f;
 }
 
 // (Re)allocates the work queues for a trace depth and a call that issues `paths` top-level tasks.
@@ -1569,11 +1618,8 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     const DCamera cam = view ? view->cam : s->ks.cam;
     const uint64_t n_paths = (uint64_t)((cam.resI + 7) / 8) * (uint64_t)((cam.resJ + 7) / 8) * 64u * (uint64_t)prm->sample_count;
     {
-        // worst-case shadow / probe tasks one task of depth 0 can emit (see chunk_for below)
-        uint64_t r0 = s->has_scatter ? (uint64_t)((double)s->max_segment * prm->mr) + 1 : 0;
-        uint64_t sh = (uint64_t)s->n_lights * prm->lsamples * (1 + r0);
-        uint64_t pr = r0 * (uint64_t)s->n_lights * (s->has_inside ? 16 : 1);
-        int rc = ensure_queues(s, prm->max_depth, n_paths, (uint64_t)std::max(prm->hsamples, 1) + r0, sh, pr);
+        const FanOut f0 = fan_out(s, prm, 0);
+        int rc = ensure_queues(s, prm->max_depth, n_paths, f0.kids, f0.shadows, f0.probes);
         if (rc) return rc;
     }
     KScene ks = s->ks;  // (after ensure_queues: it sets the spill area and stack capacity of ks.tm)
@@ -1610,22 +1656,15 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     const dim3 sgrid(s->sgrid), sblock(WAPT_SBLOCK);
     const dim3 vgrid(s->cus * env_u32("WAPT_VBLOCKS_PER_CU", 2048u / WAPT_VBLOCK)), vblock(WAPT_VBLOCK);
 
-    // worst-case fan-out of one task of depth d (sizes the chunk taken from R[d])
+    // fan-out of one task of depth d (sizes the chunk taken from R[d])
     const int L = s->n_lights;
-    auto rms_max = [&](int d) -> uint64_t {
-        if (!s->has_scatter) return 0;
-        return (uint64_t)((double)s->max_segment * prm->mr / (d + 1.0)) + 1;
-    };
     auto chunk_for = [&](int d) -> uint32_t {
-        uint64_t r = rms_max(d);
-        uint64_t kids = (uint64_t)std::max(prm->hsamples, 1) + r;
-        uint64_t shadows = (uint64_t)L * prm->lsamples * (1 + r);
-        uint64_t probes = r * (uint64_t)L * (s->has_inside ? 16 : 1);
+        const FanOut f = fan_out(s, prm, d);
         uint64_t c = s->capR;
-        if (d < td) c = std::min<uint64_t>(c, s->capR / kids);
-        if (shadows) c = std::min<uint64_t>(c, s->capS / shadows);
-        if (probes) c = std::min<uint64_t>(c, s->capP / probes);
-        if (r) c = std::min<uint64_t>(c, s->kq.capQM / r);
+        if (d < td) c = std::min<uint64_t>(c, s->capR / f.kids);
+        if (f.shadows) c = std::min<uint64_t>(c, s->capS / f.shadows);
+        if (f.probes) c = std::min<uint64_t>(c, s->capP / f.probes);
+        if (f.marches) c = std::min<uint64_t>(c, s->kq.capQM / f.marches);
         return (uint32_t)c;
     };
     for (int d = 0; d <= td; d++)
@@ -1676,19 +1715,50 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         rays_trace += n;
         n_trace_launches++;
         tm.run(FAM_SHADE, [&] { hipLaunchKernelGGL(k_surface, sgrid, sblock, 0, st, ks, q, kp, d, start, n); });
-        if (s->has_scatter) {
-            tm.run(FAM_VOLUME, [&] {
-                hipLaunchKernelGGL(k_expand, vgrid, vblock, 0, st, ks, q, kp, d, start);
-                hipLaunchKernelGGL(k_volume, vgrid, vblock, 0, st, ks, q, kp, d, start);
-            });
-            tm.run(FAM_PROBE, [&] { hipLaunchKernelGGL(k_probe, grid, block, 0, st, ks, q); });
-        }
-        {
+        auto run_shadow = [&] {
             tm.run(FAM_SHADOW, [&] {
                 if (prm->profile & 2) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, st, ks, q);
                 else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, st, ks, q);
             });
+        };
+        if (s->has_scatter) {
+            // The march samples of the step are counted before any of them emits: the step's queues were sized by
+            // bounds (fan_out), the counts are exact.  The samples are marched in slices that fit the shadow and probe
+            // queues (normally one), each followed by the kernels that drain those queues.
+            tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_expand, vgrid, vblock, 0, st, ks, q, kp, d, start); });
+            HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            const uint64_t M = s->h_cnt[CNT_QM];
+            uint64_t s_used = std::min(s->h_cnt[CNT_S], s->capS);
+            const uint64_t kids_now = d < td ? s->h_cnt[CNT_R(d + 1)] : 0;
+            if (M > s->kq.capQM || (d < td && kids_now + M > s->capR))
+                return wapt_fail(WAPT_E_LIMIT, "a step has more march samples (" + std::to_string(M) +
+                                                   ") than the queues were sized for: a segment inside an object is longer than the object's box");
+            const uint64_t sh_per = s->global_scatters ? (uint64_t)L * prm->lsamples : 0;
+            const uint64_t pr_per = (uint64_t)L * (s->has_inside ? 16 : 1);
+            uint64_t m0 = 0;
+            while (m0 < M) {
+                uint64_t ms = M - m0;
+                if (sh_per) ms = std::min(ms, (s->capS - s_used) / sh_per);
+                if (pr_per) ms = std::min(ms, (uint64_t)s->capP / pr_per);
+                if (ms == 0) {
+                    if (s_used == 0) return wapt_fail(WAPT_E_LIMIT, "shadow queue smaller than the fan-out of one march sample");
+                    run_shadow();  // make room: drain what the surface kernel emitted
+                    hipLaunchKernelGGL(k_reset_sp, dim3(1), dim3(64), 0, st, s->d_cnt);
+                    s_used = 0;
+                    continue;
+                }
+                tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_volume, vgrid, vblock, 0, st, ks, q, kp, d, start, (uint32_t)m0, (uint32_t)ms); });
+                tm.run(FAM_PROBE, [&] { hipLaunchKernelGGL(k_probe, grid, block, 0, st, ks, q); });
+                m0 += ms;
+                if (m0 < M) {
+                    run_shadow();
+                    hipLaunchKernelGGL(k_reset_sp, dim3(1), dim3(64), 0, st, s->d_cnt);
+                    s_used = 0;
+                }
+            }
         }
+        run_shadow();
         n_shadow_launches++;
         if (d < td) {
             HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
