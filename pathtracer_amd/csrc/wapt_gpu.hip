@@ -371,6 +371,17 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene s
     if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
 }
 
+// Does volumeScattering() march the segment of this task (cpp:221-230, 290, 454)?  A miss is lit through the GLOBAL
+// medium up to the world sphere, a hit through the medium the task travels in.
+__device__ __forceinline__ bool segment_marched(const KScene& sc, const HitCtx& c) {
+    if (c.tri == 0xffffffffu) {
+        const DMaterial& g = sc.mats[sc.n_objects];
+        V3 rel = c.o - ld3(sc.wc);
+        return g.scatters && (mag(rel) < sc.wr);
+    }
+    return medium_of(sc, info_medium(c.info)).scatters != 0u;
+}
+
 // radiance() from the closest hit on (cpp:218-290) for every task of the step, in one pass over the
 // queue: miss handling, roulette, emission, then the surface event of the hit material -
 // Lambert: directReflection (cpp:345-381) + indirectReflection (cpp:383-405); mirror: the specular
@@ -404,10 +415,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
             set_hit(sc, h, c);
             DBG(c.pixel, "head d=%d key=%08x o=(%.6f %.6f %.6f) dir=(%.7f %.7f %.7f) t=%.6f tri=%u P=(%.6f %.6f %.6f) obj=%d beta=%g\n", depth, c.key, c.o.x, c.o.y, c.o.z, c.dir.x, c.dir.y, c.dir.z, c.t, c.tri, c.P.x, c.P.y, c.P.z, c.obj, c.beta.x);
             if (c.tri == 0xffffffffu) {
-                // cpp:221-230: the segment to the world sphere is lit through the GLOBAL medium
-                const DMaterial& g = sc.mats[sc.n_objects];
-                V3 rel = c.o - ld3(sc.wc);
-                toV = g.scatters && (mag(rel) < sc.wr);
+                toV = segment_marched(sc, c);
             } else {
                 const DMaterial& m = sc.mats[c.obj];
                 float xs = wapt_rand(c.stream, WAPT_DIM_SURF);
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                     else if (m.flags & WAPT_MAT_SPECULAR) kind = MIRROR;
                     else if (m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) kind = DIELECTRIC;
                 }
-                toV = medium_of(sc, info_medium(c.info)).scatters != 0u;
+                toV = segment_marched(sc, c);
                 N1f = c.entering ? c.N : -c.N;
                 if (kind == LAMBERT) {
                     kd = ld3(m.kd);
@@ -584,6 +592,38 @@ __device__ __forceinline__ uint32_t block_push_count(uint32_t* counter, uint32_t
     }
     __syncthreads();
     return s_offN[wave] + x - count;
+}
+
+// The number of march samples the step's tasks will produce, before any of them is shaded: the launches of a
+// scene with media are sized by bounds on the segment lengths, and a segment inside an OPEN mesh can exceed its
+// bound; the host cuts the step down to what fits if the count says so.  Same arithmetic as k_surface (refined hit
+// distance) and k_expand, so the count is exact.  out[0] += march samples, out[1] += marched segments.
+__global__ __launch_bounds__(WAPT_VBLOCK) void k_count(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n,
+                                                       unsigned long long* out) {
+    unsigned long long mine = 0, segs = 0;
+    GRID_LOOP(i, n) {
+        if (i < n) {
+            HitCtx c = {};
+            load_task(q, depth, start, i, c);
+            uint2 h = q.hits[i];
+            if (h.y != 0xffffffffu) h.x = f2u(refine_distance(sc.tm.tris, h.y, c.o, c.dir, WAPT_TRACE_BIAS, u2f(h.x)));
+            set_hit(sc, h, c);
+            if (segment_marched(sc, c)) {
+                mine += (unsigned long long)march_segment(sc, p, c, depth).rms;
+                segs++;
+            }
+        }
+    }
+    __shared__ unsigned long long s_sum[2];
+    if (threadIdx.x == 0) s_sum[0] = s_sum[1] = 0ull;
+    __syncthreads();
+    if (mine) atomicAdd(&s_sum[0], mine);
+    if (segs) atomicAdd(&s_sum[1], segs);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum[1]) {
+        atomicAdd(&out[0], s_sum[0]);
+        atomicAdd(&out[1], s_sum[1]);
+    }
 }
 
 // One entry (task, sample) per march sample of the step's marched segments: the march kernel then has one
@@ -1443,8 +1483,8 @@ int ensure_spill(wapt_scene* s) {
 }
 
 // What one task of depth d emits at most.  A task marches one segment: through the global medium (any length up to
-// max_segment; light sampling and one probe per light and march sample) or inside an object (closed objects: no longer
-// than the object's box diagonal; 16 probes per light and march sample).  A segment that lies inside an OPEN mesh can
+// max_segment) or inside an object (closed objects: no longer than the object's box diagonal); a march sample emits
+// a shadow walk and a probe per light, or 16 probes per light when the segment ends on the object's own back face.  A segment that lies inside an OPEN mesh can
 // exceed that bound: the render loop checks the exact number of march samples of a step before it emits anything
 // and refuses the step then.
 struct FanOut {
@@ -1457,7 +1497,7 @@ FanOut fan_out(const wapt_scene* s, const wapt_render_params* prm, int d) {
     const uint64_t L = (uint64_t)s->n_lights;
     f.marches = std::max(r_out, r_in);
     f.kids = (uint64_t)std::max(prm->hsamples, 1) + f.marches;
-    f.shadows = L * prm->lsamples * (1 + r_out);
+    f.shadows = L * prm->lsamples * (1 + f.marches);  // (a segment in an object's medium that ends on a front face samples the lights too)
     f.probes = L * std::max(r_out, 16 * r_in);
     return f;
 }
@@ -1707,11 +1747,34 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         uint32_t n = std::min(have[d], chunk_for(d));
         uint32_t start = have[d] - n;
         have[d] = start;
-        hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, d < td ? CNT_R(d + 1) : -1, 0u);
-        tm.run(FAM_TRACE, [&] {
-            if (prm->profile & 2) hipLaunchKernelGGL(k_trace<true>, grid, block, 0, st, ks, q, d, start, n);
-            else hipLaunchKernelGGL(k_trace<false>, grid, block, 0, st, ks, q, d, start, n);
-        });
+        for (;;) {
+            hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, d < td ? CNT_R(d + 1) : -1, 0u);
+            tm.run(FAM_TRACE, [&] {
+                if (prm->profile & 2) hipLaunchKernelGGL(k_trace<true>, grid, block, 0, st, ks, q, d, start, n);
+                else hipLaunchKernelGGL(k_trace<false>, grid, block, 0, st, ks, q, d, start, n);
+            });
+            if (!s->has_inside) break;
+            // Scenes with a scattering object: chunk_for() bounds a segment inside an object by the object's box,
+            // which an open mesh can exceed.  The exact number of march samples of the step is counted before anything
+            // is shaded; a step that would not fit is cut down and traced again.
+            unsigned long long h_m[2] = {0, 0};
+            HIPCHK(hipMemsetAsync(s->d_rays + 14, 0, 2 * sizeof(unsigned long long), st));
+            tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_count, vgrid, vblock, 0, st, ks, q, kp, d, start, n, s->d_rays + 14); });
+            HIPCHK(hipMemcpyAsync(h_m, s->d_rays + 14, sizeof(h_m), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            const uint64_t M = h_m[0], kids_surface = (uint64_t)n * (uint64_t)std::max(prm->hsamples, 1);
+            const bool fits = M <= s->kq.capQM && (d >= td || kids_surface + M <= s->capR);
+            if (fits) break;
+            if (n <= 64)
+                return wapt_fail(WAPT_E_LIMIT, "the march samples of 64 tasks (" + std::to_string(M) + ") do not fit the queues");
+            double ratio = (double)s->kq.capQM / (double)M;
+            if (d < td) ratio = std::min(ratio, (double)s->capR / (double)(kids_surface + M));
+            uint32_t n_new = std::max(64u, (uint32_t)((double)n * ratio * 0.8) & ~63u);
+            n_new = std::min(n_new, n - 64u);
+            start += n - n_new;
+            have[d] = start;
+            n = n_new;
+        }
         rays_trace += n;
         n_trace_launches++;
         tm.run(FAM_SHADE, [&] { hipLaunchKernelGGL(k_surface, sgrid, sblock, 0, st, ks, q, kp, d, start, n); });
@@ -1734,7 +1797,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
             if (M > s->kq.capQM || (d < td && kids_now + M > s->capR))
                 return wapt_fail(WAPT_E_LIMIT, "a step has more march samples (" + std::to_string(M) +
                                                    ") than the queues were sized for: a segment inside an object is longer than the object's box");
-            const uint64_t sh_per = s->global_scatters ? (uint64_t)L * prm->lsamples : 0;
+            const uint64_t sh_per = (uint64_t)L * prm->lsamples;
             const uint64_t pr_per = (uint64_t)L * (s->has_inside ? 16 : 1);
             uint64_t m0 = 0;
             while (m0 < M) {

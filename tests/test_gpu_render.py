@@ -202,3 +202,35 @@ def test_shadow_walk_shortcuts_equal_the_general_path(name, monkeypatch):
     general, st_gen = gpu_render(sc, spp, seed=3, **kw)
     np.testing.assert_allclose(fast, general, rtol=2e-4, atol=1e-6)
     assert st_fast.rays == st_gen.rays
+
+
+def _open_milk_sheet_scene(res=(32, 32)):
+    """The box with an OPEN sheet of the milk material right in front of the camera: every path enters the medium
+    through the sheet and then travels to a wall, so the marched segments are several times longer than the sheet's
+    box diagonal - the bound that sizes the launches of scenes with media (closed objects keep it, an open mesh
+    need not)."""
+    from pathtracer_amd import meshes
+    from pathtracer_amd.scene import Scene, area_light, camera, material
+    mats, ms = scenes._box()
+    v = np.array([[225, 225, 100], [225, 325, 100], [325, 325, 100], [325, 225, 100]], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int32)  # geometric normal -z: towards the camera
+    ms.append(meshes.expand(v, f))
+    mats.append(material("dielectricsss", **scenes.MILK))
+    cam = camera(P=(275, 275, 0), at=(275, 275, 100), up=(0, 1, 0), fov=40.0, res=res, width=1.0)
+    return Scene(cam, [area_light(**scenes.LIGHT)], mats, ms, td=3, me=0.0, mr=0.05)
+
+
+def test_march_samples_beyond_the_sizing_bound_are_marched_in_slices(monkeypatch):
+    """Segments inside an open mesh exceed the bound the queues were sized by; the exact count of a step's march
+    samples is known before anything is emitted, and the samples are then marched in slices that fit the shadow and
+    probe queues.  Small queues force several slices per step; the image must not change, and must match the checker."""
+    sc = _open_milk_sheet_scene()
+    ref_gpu, st0 = gpu_render(sc, 2, seed=5)
+    monkeypatch.setenv("WAPT_PROBE_CAP", str(1 << 16))
+    monkeypatch.setenv("WAPT_SHADOW_CAP", str(1 << 16))
+    sliced, st1 = gpu_render(sc, 2, seed=5)
+    np.testing.assert_allclose(sliced, ref_gpu, rtol=2e-4, atol=1e-6)
+    assert st1.rays == st0.rays and st1.stack_overflows == 0
+    monkeypatch.delenv("WAPT_PROBE_CAP")
+    monkeypatch.delenv("WAPT_SHADOW_CAP")
+    same_seed_check(sc, 2, seed=5, frac=0.99)
