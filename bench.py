@@ -171,6 +171,11 @@ def main():
                            "avg_launch_ms": avg_ms, "launches_per_step": int(n_launch),
                            "grays_per_s_in_kernel": rays_per_launch / (avg_ms * 1e-3) / 1e9,
                            "kernel_ms_per_step": fam, "lane_utilisation": util, "shadow_rays_per_step": int(shadow_rays)}
+        if traffic:
+            # memory-side rate of the same kernel (PMC passes of the round profile): what HBM / Infinity Cache
+            # actually carried, next to the algorithmic rate above
+            out["roofline"]["traffic_gbs"] = traffic / (avg_ms * 1e-3) / 1e9
+            out["roofline"]["traffic_frac"] = out["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
