@@ -1,0 +1,64 @@
+"""The GPU path against what the reference itself produced, without the CPU checker in between:
+  * tests/golden/cornell_empty_known_answers.json - linear-radiance pixel values of the reference's estimator for the
+    bundled box scene (60x60, two runs of 4096 spp);
+  * tests/golden/published_image_patches.json - 9x9 patch means of the published, tone-mapped 600x600 renders
+    (images/*.bmp), restricted to the part of the picture above the objects.
+The GPU renders at the fixtures' own resolutions and at sample counts the CPU checker could not afford, so the
+tolerances are the fixtures' (the reference's run-to-run spread), not the render's noise."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _render(scene, spp, seed):
+    from pathtracer_amd import renderer
+    c = renderer.wa_content(scene)
+    try:
+        r = renderer.udp_renderer(c, spp, 1, 1, 1, seed=seed)
+        return r.render(), r.stats
+    finally:
+        c.close()
+
+
+def test_gpu_reproduces_the_known_answers_of_the_reference_estimator():
+    fb, st = _render(scenes.cornell(res=(60, 60), spheres=False), 16384, seed=101)
+    k = json.load(open(os.path.join(GOLD, "cornell_empty_known_answers.json")))
+    np.testing.assert_allclose(fb.reshape(-1, 3).mean(0), k["image_mean"], rtol=0.01)
+    assert abs(st.rays / (60 * 60 * 16384.0) - k["rays_per_path"]) < 0.1
+    for p in k["pixels"]:
+        got, want = fb[p["j"], p["i"]], np.array(p["rgb"])
+        # the reference's own 4096-spp runs differ by 2.1 % (1 sigma); 3 sigma + 0.005 absolute for the dim ceiling
+        assert np.all(np.abs(got - want) <= 0.065 * want + 0.005), (p["what"], got, want)
+    light = [p for p in k["pixels"] if p["what"].startswith("light")][0]
+    np.testing.assert_allclose(fb[light["j"], light["i"]], light["rgb"], rtol=2e-3)
+
+
+def test_gpu_matches_the_published_images_above_the_objects():
+    g = json.load(open(os.path.join(GOLD, "published_image_patches.json")))
+    n = 600
+    fb, _ = _render(scenes.cornell(res=(n, n), spheres=False), 1024, seed=5)
+    tm = np.clip(np.power(np.maximum(fb, 0), 0.45), 0, 1) * 255.0  # myRenderer.cpp:174-185, 713
+    for name in ("dragonChrome.bmp", "cornellBox.bmp"):
+        lit, dim = [], []
+        for p in g["images"][name]["patches"]:
+            i, j = int(p["col"]), n - 1 - int(p["row"])  # image row 0 is the top, frame buffer row 0 the bottom
+            want = np.array(p["rgb"])
+            if want.max() > 250:  # saturated (the light)
+                continue
+            got = tm[j - 4:j + 5, i - 4:i + 5].reshape(-1, 3).mean(0)
+            err = np.abs(got - want) / (want + 8.0)
+            # walls lit directly by the lamp do not care about the objects below; the ceiling is lit only by light
+            # bounced off the floor, part of which the published scenes' objects intercept
+            (lit if want.max() >= 150 else dim).append(err)
+        lit, dim = np.array(lit), np.array(dim)
+        assert len(lit) >= 12 and len(dim) >= 6
+        assert lit.max() < 0.06, (name, lit.max())
+        assert dim.max() < 0.25, (name, dim.max())
