@@ -148,6 +148,98 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
     t.hflag = 0u;
 }
 
+// Wave-private LDS of the cooperative triangle phase: the closest hit found so far per lane's ray
+// ((distance bits << 32) | triangle, so a 64-bit minimum keeps the nearest) and the list of pending
+// (lane, triangle-of-its-set) pairs of the step.
+// 1: the triangle phase of the kernels is the cooperative one (tri_phase_coop); 0: the sequential loop
+#ifndef WAPT_COOP
+#define WAPT_COOP 1
+#endif
+#ifndef WAPT_COOP_PER_LANE
+#define WAPT_COOP_PER_LANE 4
+#endif
+struct CoopLds {
+    unsigned long long best[64];
+    uint16_t items[64 * WAPT_COOP_PER_LANE];
+};
+
+// Triangle phase with the tests spread over the wave: every pending (ray, triangle) pair of the step becomes
+// one item, the items are dealt to the lanes 64 at a time, a lane fetches the ray of the item's owner across
+// the wave and tests the triangle, and a 64-bit minimum per owner keeps the nearest hit.  (One ray's leaf with
+// three triangles costs the sequential loop three trips with one lane busy; here the step's ~57 tests take one
+// round.)  A lane contributes at most WAPT_COOP_PER_LANE triangles per step and keeps the rest pending.
+// (Closest-hit searches only.  Shadow walks keep the sequential loop: they stop at the first opaque hit, keep 41 % of
+// that loop's lanes busy and need the flag word of the hit; spread over the wave they were 14 % slower.)
+template <bool COUNT>
+__device__ __forceinline__ void tri_phase_coop(const TraceMem& m, Trav& t, bool pending, CoopLds* cl, TraceCount& cnt) {
+    const uint32_t lane = __lane_id();
+    const uint32_t bits = pending ? t.T.y : 0u;
+    uint32_t rest = bits;
+#pragma unroll
+    for (int j = 0; j < WAPT_COOP_PER_LANE; j++) rest &= rest - 1u;
+    const uint32_t mine = bits ^ rest;  // the lowest WAPT_COOP_PER_LANE pending triangles
+    const uint32_t n_mine = (uint32_t)__popc(mine);
+    // exclusive prefix sum of the (small) counts from one ballot per bit of the count: no LDS round trips
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int bit = 0; (1 << bit) <= WAPT_COOP_PER_LANE; bit++) {
+        const unsigned long long mk = __ballot((n_mine >> bit) & 1u);
+        off += (uint32_t)__popcll(mk & ((1ull << lane) - 1ull)) << bit;
+        total += (uint32_t)__popcll(mk) << bit;
+    }
+    for (uint32_t b = mine; b; b &= b - 1u) cl->items[off++] = (uint16_t)(lane | (((uint32_t)__ffs((int)b) - 1u) << 6));
+    cl->best[lane] = ((unsigned long long)__float_as_uint(t.tmax) << 32) | (unsigned long long)t.hit;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (COUNT) cnt.ttrips += (total + 63u) >> 6;
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t idx = base + lane;
+        const bool valid = idx < total;
+        const uint32_t item = valid ? (uint32_t)cl->items[idx] : 0u;
+        const int src = (int)(item & 63u);
+        const uint32_t k = item >> 6;
+        const uint32_t tbase = (uint32_t)__shfl((int)t.T.x, src);
+        const V3 o = v3(__shfl(t.o.x, src), __shfl(t.o.y, src), __shfl(t.o.z, src));
+        const V3 d = v3(__shfl(t.d.x, src), __shfl(t.d.y, src), __shfl(t.d.z, src));
+        const float tmin = __shfl(t.tmin, src);
+        const float tmax = __uint_as_float((uint32_t)(cl->best[src] >> 32));
+        if (valid) {
+            const uint32_t ti = tbase + k;
+            const float4* tp = m.tris + (uint32_t)(ti * 3u);
+            float4 a = tp[0], b = tp[1], c = tp[2];
+            if (COUNT) cnt.tris++;
+            // the triangle test of the sequential loop below (Embree's form, see there), on the fetched ray
+            V3 p0 = v3(a.x, a.y, a.z), p1 = v3(a.w, b.x, b.y), p2 = v3(b.z, b.w, c.x);
+            V3 e1 = p0 - p1, e2 = p2 - p0;
+            V3 Ng = cross(e2, e1);
+            V3 Cv = p0 - o;
+            V3 R = cross(Cv, d);
+            float den = dot(Ng, d);
+            float absDen = fabsf(den);
+            float sgn = den < 0.f ? -1.0f : 1.0f;
+            float U = dot(R, e2) * sgn;
+            float V = dot(R, e1) * sgn;
+            float Tn = dot(Ng, Cv) * sgn;
+            if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * tmin < Tn && Tn <= absDen * tmax) {
+                // search distance only (the final one is re-evaluated in fp64, see refine_distance): the 1-ulp
+                // reciprocal saves the ten-instruction IEEE division
+                const unsigned long long key = (unsigned long long)__float_as_uint(Tn * __builtin_amdgcn_rcpf(absDen)) << 32;
+                atomicMin(&cl->best[src], key | (unsigned long long)ti);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (pending) {
+        unsigned long long r = cl->best[lane];
+        t.tmax = __uint_as_float((uint32_t)(r >> 32));
+        t.hit = (uint32_t)r;
+        t.T.y = rest;
+    }
+}
+
 // One traversal step of a wave.  A lane without pending triangles visits its nearest pending inner
 // child (popping the stack when its current group is exhausted); triangles that the visited nodes
 // expose are collected in t.T and tested when at least `tri_quorum` lanes of the wave have some or no
@@ -160,9 +252,10 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
 // SHADOW: the caller only wants to know what a shadow walk needs, so the search stops at the first
 // opaque triangle (bit 0 of the triangle record's last word) closer than t.tblock: whatever else lies
 // in front of it, the walk from A to B ends with zero visibility.
-template <bool COUNT, bool SHADOW = false>
+template <bool COUNT, bool SHADOW = false, bool COOP = false>
 __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have, uint2* lds, uint32_t glane,
-                                          TraceCount& cnt) {
+                                          TraceCount& cnt, CoopLds* coop = nullptr) {
+    static_assert(!(SHADOW && COOP), "shadow walks use the sequential triangle loop");
     const int tri_quorum = m.tri_quorum;
     bool descend = have && t.T.y == 0u;
     if (COUNT) {
@@ -225,7 +318,9 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
     bool pending = have && t.T.y != 0u;
     bool can_descend = have && t.T.y == 0u && ((t.G.y & 0xff000000u) != 0u || t.sp > 0);
     int waiting = (int)__popcll(__ballot(pending));
-    if (waiting >= tri_quorum || (waiting > 0 && !__any(can_descend))) {
+    if (COOP) {
+        if (waiting > 0) tri_phase_coop<COUNT>(m, t, pending, coop, cnt);
+    } else if (waiting >= tri_quorum || (waiting > 0 && !__any(can_descend))) {
         // (lanes without a ray, whose state is stale, stay out: `bits` is zero for them)
         uint32_t bits = pending ? t.T.y : 0u;
         if (COUNT) {

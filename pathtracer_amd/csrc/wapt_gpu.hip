@@ -337,6 +337,8 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_raygen(KScene sc, KQueues q, KP
 template <bool COUNT>
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene sc, KQueues q, int depth, uint32_t start, uint32_t n) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
+    __shared__ CoopLds s_coop[WAPT_BLOCK / 64];
+    CoopLds* coop = &s_coop[threadIdx.x >> 6];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     TraceCount tc = {};
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED);
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene s
             have = true;
         }
         if (!__any(have)) break;
-        if (trav_step<COUNT>(sc.tm, t, have, &s_stack[threadIdx.x], glane, tc)) {
+        if (trav_step<COUNT, false, WAPT_COOP>(sc.tm, t, have, &s_stack[threadIdx.x], glane, tc, coop)) {
             q.hits[cur] = make_uint2(f2u(t.tmax), t.hit);  // fp32 distance; k_head refines it
             have = false;
         }
@@ -964,8 +966,12 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
 // second ray.
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
-    __shared__ float4 s_stage[WAPT_BLOCK];
-    float4* astage = &s_stage[threadIdx.x & ~63u];
+    __shared__ union WaveLds {
+        float4 stage[64];
+        CoopLds coop;
+    } s_wave[WAPT_BLOCK / 64];
+    float4* astage = s_wave[threadIdx.x >> 6].stage;
+    CoopLds* coop = &s_wave[threadIdx.x >> 6].coop;
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = min(q.cnt[CNT_P], q.capP);
     TraceCount tc = {};
@@ -989,7 +995,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
         if (!__any(have_task)) break;
         bool lit = false;
         V3 contrib = v3(0, 0, 0);
-        if (trav_step<false>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
+        if (trav_step<false, false, WAPT_COOP>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc, coop)) {
             have_ray = false;
             have_task = false;
             const uint32_t tri = t.hit;
@@ -1050,6 +1056,8 @@ template <bool COUNT>
 __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const float4* rays, uint32_t n, float* hits,
                                                           unsigned long long* counters, uint32_t* feed_counters) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
+    __shared__ CoopLds s_coop[WAPT_BLOCK / 64];
+    CoopLds* coop = &s_coop[threadIdx.x >> 6];
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     TraceCount tc = {};
     WaveFeed feed = wave_feed(n, feed_counters);
@@ -1065,7 +1073,7 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const flo
             have = true;
         }
         if (!__any(have)) break;
-        if (trav_step<COUNT>(tm, t, have, &s_stack[threadIdx.x], glane, tc)) {
+        if (trav_step<COUNT, false, WAPT_COOP>(tm, t, have, &s_stack[threadIdx.x], glane, tc, coop)) {
             have = false;
             float* h = hits + 6 * (size_t)cur;
             h[0] = trav_finish(tm, t);
