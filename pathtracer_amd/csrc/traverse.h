@@ -18,7 +18,9 @@
 #include "device_math.h"
 
 #define WAPT_BLOCK 256
+#ifndef WAPT_LDS_STACK
 #define WAPT_LDS_STACK 8
+#endif
 #define WAPT_STACK_CAP 32
 // waves per SIMD the register allocator must leave room for (second argument of __launch_bounds__).
 // Measured on dragonChrome 1080p (ms per 64 spp, closest-hit / shadow kernel): 6 and 5 waves with 6 blocks
