@@ -134,6 +134,10 @@ typedef struct wapt_stats {
     uint64_t trace_wave_steps, trace_node_steps, trace_tri_trips;
     /* the same five tallies for the rays of the shadow walks */
     uint64_t shadow_node_visits, shadow_tri_tests, shadow_wave_steps, shadow_node_steps, shadow_tri_trips;
+    /* closest-hit queries of the reference's estimator that were answered without a search and are not in `rays`:
+     * directLightHit / directLightingSingleScatter probes (cpp:631-687) only ask whether the closest hit is one given
+     * light; a ray that misses that light's quad (or a light without geometry) cannot have it */
+    uint64_t queries_decided;
 } wapt_stats;
 
 typedef struct wapt_ray {

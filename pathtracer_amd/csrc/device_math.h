@@ -54,7 +54,9 @@ struct DLight {
     float area, radius;
     float Li[3];      // radiance: area 0.5*power/area/pi, sphere power/(4 pi r^2)/pi
     float centre[3];  // getCentre()
-    float pad;
+    // the light object's triangles in the BVH (filled on the device after the tree is built): an area light's quad
+    // is two, a sphere light has none (src/content.cpp:42-50 gives only area lights a geometry)
+    int32_t ntri, tri0, tri1;
 };
 
 struct DCamera {

@@ -382,6 +382,42 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
     return have && t.T.y == 0u && (t.G.y & 0xff000000u) == 0u && t.sp == 0;
 }
 
+// One triangle against one ray with the arithmetic of the search loops above (Embree's form): true and the
+// search-precision distance if the ray hits it in (tmin, tmax].
+__device__ __forceinline__ bool tri_hit_one(const float4* __restrict__ tris, uint32_t ti, V3 o, V3 d, float tmin, float tmax, float* th) {
+    const float4* tp = tris + (uint32_t)(ti * 3u);
+    float4 a = tp[0], b = tp[1], c = tp[2];
+    V3 p0 = v3(a.x, a.y, a.z), p1 = v3(a.w, b.x, b.y), p2 = v3(b.z, b.w, c.x);
+    V3 e1 = p0 - p1, e2 = p2 - p0;
+    V3 Ng = cross(e2, e1);
+    V3 Cv = p0 - o;
+    V3 R = cross(Cv, d);
+    float den = dot(Ng, d);
+    float absDen = fabsf(den);
+    float sgn = den < 0.f ? -1.0f : 1.0f;
+    float U = dot(R, e2) * sgn;
+    float V = dot(R, e1) * sgn;
+    float Tn = dot(Ng, Cv) * sgn;
+    if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * tmin < Tn && Tn <= absDen * tmax) {
+        *th = Tn * __builtin_amdgcn_rcpf(absDen);
+        return true;
+    }
+    return false;
+}
+
+// Where a ray meets the two triangles tri0, tri1 of a light's quad, if it does: the nearer hit.
+__device__ __forceinline__ bool quad_hit(const float4* __restrict__ tris, uint32_t tri0, uint32_t tri1, V3 o, V3 d, float tmin,
+                                         float tmax, float* th, uint32_t* tri) {
+    float t0 = 0.f, t1 = 0.f;
+    const bool h0 = tri_hit_one(tris, tri0, o, d, tmin, tmax, &t0);
+    const bool h1 = tri_hit_one(tris, tri1, o, d, tmin, tmax, &t1);
+    if (!h0 && !h1) return false;
+    const bool first = h0 && (!h1 || t0 <= t1);
+    *th = first ? t0 : t1;
+    *tri = first ? tri0 : tri1;
+    return true;
+}
+
 // Distance of a hit: the same quotient T/|den| as in the search, re-evaluated in fp64 from the float
 // vertices (fp32 shows 1e-5-level relative error on thin, distant triangles; the acceptance bar for
 // hit distances is 1e-5).  `t32` is the fp32 distance the search produced (returned if the fp64 value

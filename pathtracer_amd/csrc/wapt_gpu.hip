@@ -288,6 +288,17 @@ __global__ void k_reset(uint32_t* cnt, int r_slot, uint32_t r_value) {
     if (r_slot >= 0 && t == 0) cnt[r_slot] = r_value;
 }
 
+// Which triangles of the tree belong to each light object (DLight::ntri, tri0, tri1; see k_probe).
+__global__ void k_light_tris(const float4* tris, uint32_t n_tris, int n_lights, DLight* lights) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tris) return;
+    int obj = (int)__float_as_uint(tris[(size_t)i * 3 + 2].y);
+    if (obj >= n_lights) return;
+    int k = atomicAdd(&lights[obj].ntri, 1);
+    if (k == 0) lights[obj].tri0 = (int)i;
+    if (k == 1) lights[obj].tri1 = (int)i;
+}
+
 // Between two slices of a step's march samples: the shadow and probe queues and the feeds of their kernels start over.
 __global__ void k_reset_sp(uint32_t* cnt) {
     uint32_t t = threadIdx.x;
@@ -650,6 +661,7 @@ __global__ __launch_bounds__(WAPT_VBLOCK) void k_expand(KScene sc, KQueues q, KP
 
 // volumeScattering (cpp:429-621): one march sample of the segment of one task per lane
 __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t m0, uint32_t n) {
+    uint32_t skipped = 0;  // probes decided here (tallied like those k_probe decides)
     GRID_LOOP(j, n) {
         const bool act = j < n;
         HitCtx c = {};
@@ -734,7 +746,11 @@ __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScen
                         const V3 pdir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
                         const V3 pw = (4.0f * WAPT_PI) * cs;
                         uint32_t* const counters[3] = {&q.cnt[CNT_S], &q.cnt[CNT_P], &q.cnt[CNT_R(depth + 1)]};
-                        const bool preds[3] = {emit, act && !inside && finite_dir(pdir) && !is_zero(pw), cemit && !child_done};
+                        // (a light without geometry is never the closest hit of a ray: its probes are not emitted)
+                        const bool probe = act && !inside && finite_dir(pdir) && !is_zero(pw);
+                        const bool reachable = !sc.fast_probe || L.ntri != 0;
+                        if (probe && !reachable) skipped++;
+                        const bool preds[3] = {emit, probe && reachable, cemit && !child_done};
                         uint32_t slots[3];
                         block_push3(counters, preds, slots);
                         if (preds[0]) write_shadow(q, slots[0], S, LP, wt, c.pixel, tgt);
@@ -772,6 +788,8 @@ __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScen
             if (!child_done) push_radiance(q, depth + 1, cemit, S, cdir, cbeta, c.pixel, cinfo, ckey);
         }
     }
+    skipped = wave_sum(skipped);
+    if (lane_id() == 0 && skipped) atomicAdd(&q.rays[7], (unsigned long long)skipped);
 }
 
 // Adds the colours of the lanes with `pred` to their pixels' sums.  The red, green and blue of one pixel
@@ -964,6 +982,14 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
 // directLightHit (cpp:670-687) and directLightingSingleScatter (cpp:631-665).  Lanes stream tasks like
 // k_trace; a single-scatter probe that reaches its object's surface keeps its lane for the refracted
 // second ray.
+//
+// Both estimators trace a ray and keep the result only if the closest hit is one given light.  The light's
+// quad is two triangles of the tree (DLight::tri0/1), so the question is put to them first, with the test the
+// search itself uses: a ray that misses them cannot have the light as its closest hit and is not searched at
+// all (most rays: the quad is small); one that meets them at distance tL is searched up to tL only, and the
+// search stops at the first other triangle it accepts.  A light with no geometry (sphere lights) is never
+// hit, one with another number of triangles gets the plain closest-hit search.  Queries answered without a
+// search are tallied in rays[7], not in the ray count.
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     __shared__ union WaveLds {
@@ -975,33 +1001,85 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = min(q.cnt[CNT_P], q.capP);
     TraceCount tc = {};
-    uint32_t rays = 0;
+    uint32_t rays = 0, decided = 0;
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED + 64 * WAPT_FEED_STRIDE);
     Trav t = {};
     bool have_task = false, have_ray = false;
     uint32_t task = 0;
     int stage = 0;          // 1: the ray in flight is the refracted one
     float seg0 = 0.f, F0 = 0.f;  // length of the first segment and Fresnel term at the surface
+    // the ray in flight asks for the quad of a light: its triangle there (0xffffffff: plain closest-hit search)
+    uint32_t want = 0xffffffffu;
+    int want_light = 0;
+
+    // Starts the search of a ray whose closest hit has to be light `l`, or decides it on the spot.
+    auto aim = [&](V3 o, V3 d, int l) -> bool {
+        const DLight& L = sc.lights[l];
+        want = 0xffffffffu;
+        want_light = l;
+        if (sc.fast_probe && L.ntri == 0) {
+            decided++;
+            return false;
+        }
+        if (sc.fast_probe && L.ntri == 2) {
+            float tl;
+            if (!quad_hit(sc.tm.tris, (uint32_t)L.tri0, (uint32_t)L.tri1, o, d, WAPT_TRACE_BIAS, WAPT_TFAR, &tl, &want)) {
+                decided++;
+                return false;
+            }
+            trav_begin(t, o, d, WAPT_TRACE_BIAS, tl);  // nothing beyond the quad matters
+        } else {
+            trav_begin(t, o, d, WAPT_TRACE_BIAS, WAPT_TFAR);
+        }
+        rays++;
+        return true;
+    };
+
     for (;;) {
         uint32_t idx = feed.take(!have_task);
         if (idx != 0xffffffffu) {
             float4 a = q.PA[idx], b = q.PB[idx];
-            trav_begin(t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, WAPT_TFAR);
+            const uint32_t info = f2u(b.w);
             task = idx;
             stage = 0;
-            have_task = have_ray = true;
-            rays++;
+            if ((info >> 16) == 0u) {
+                have_task = have_ray = aim(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), (int)(info & 0xffffu));
+            } else {
+                want = 0xffffffffu;
+                trav_begin(t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, WAPT_TFAR);
+                have_task = have_ray = true;
+                rays++;
+            }
         }
         if (!__any(have_task)) break;
         bool lit = false;
         V3 contrib = v3(0, 0, 0);
-        if (trav_step<false, false, WAPT_COOP>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc, coop)) {
+        bool done = trav_step<false, false, WAPT_COOP>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc, coop);
+        if (have_ray && !done && want != 0xffffffffu && t.hit != 0xffffffffu) {
+            // a triangle in front of the quad (or the quad itself, which ends the matter as well)
+            const DLight& L = sc.lights[want_light];
+            if (t.hit != (uint32_t)L.tri0 && t.hit != (uint32_t)L.tri1) {
+                have_ray = have_task = false;
+                t.G = make_uint2(0u, 0u);
+                t.T = make_uint2(0u, 0u);
+                t.sp = 0;
+            }
+        }
+        if (done) {
             have_ray = false;
             have_task = false;
-            const uint32_t tri = t.hit;
-            if (tri != 0xffffffffu) {
-                const float tmax = trav_finish(sc.tm, t);
+            uint32_t tri = t.hit;
+            float tsearch = t.tmax;
+            bool on_light = false;
+            if (want != 0xffffffffu) {
+                // searched up to the quad: the light is the closest hit unless another triangle was accepted
+                const DLight& L = sc.lights[want_light];
+                on_light = tri == 0xffffffffu || tri == (uint32_t)L.tri0 || tri == (uint32_t)L.tri1;
+                if (tri == 0xffffffffu) tri = want;  // (t.tmax is still the quad's distance then)
+            }
+            if (tri != 0xffffffffu && (want == 0xffffffffu || on_light)) {
                 const V3 S = t.o, dir = t.d;
+                const float tmax = refine_distance(sc.tm.tris, tri, S, dir, t.tmin, tsearch);
                 const uint32_t info = f2u(q.PB[task].w);
                 const float4 w4 = q.PC[task];
                 const int light = (int)(info & 0xffffu);
@@ -1036,10 +1114,8 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
                     if (!is_zero(D1) && finite_dir(dir1)) {
                         seg0 = mag(hp - S);
                         F0 = F;
-                        trav_begin(t, hp, dir1, WAPT_TRACE_BIAS, WAPT_TFAR);
                         stage = 1;
-                        have_task = have_ray = true;
-                        rays++;
+                        have_task = have_ray = aim(hp, dir1, light);
                     }
                 }
             }
@@ -1047,7 +1123,9 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
         wave_add_rgb(q.sum, astage, lit, lit ? f2u(q.PA[task].w) : 0u, contrib);
     }
     rays = wave_sum(rays);
+    decided = wave_sum(decided);
     if (lane_id() == 0 && rays) atomicAdd(q.rays, (unsigned long long)rays);
+    if (lane_id() == 0 && decided) atomicAdd(&q.rays[7], (unsigned long long)decided);
     if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
 }
 
@@ -1386,6 +1464,9 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     HIPCHK_S(hipMalloc(&s->d_lights, lights.size() * sizeof(DLight)));
     HIPCHK_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
     s->n_lights = desc->n_lights;
+    if (desc->n_lights > 0)
+        hipLaunchKernelGGL(k_light_tris, dim3((unsigned)((s->n_tris + 255) / 256)), dim3(256), 0, s->stream, (const float4*)s->d_tris,
+                           (uint32_t)s->n_tris, desc->n_lights, (DLight*)s->d_lights);
 
     // longest possible segment: everything lives inside the ball around the world
     // centre that holds the world sphere, the geometry and the camera
@@ -1428,6 +1509,8 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     s->ks.n_objects = desc->n_objects;
     // WAPT_GENERAL_SHADOW=1 sends every shadow walk through the step-by-step path (the tests compare the two)
     s->ks.fast_shadow = env_u32("WAPT_GENERAL_SHADOW", 0) ? 0 : 1;
+    // WAPT_GENERAL_PROBE=1: every probe ray gets the plain closest-hit search (the tests compare the two)
+    s->ks.fast_probe = env_u32("WAPT_GENERAL_PROBE", 0) ? 0 : 1;
     s->ks.cam = to_device(desc->camera);
     s->camera = desc->camera;
     memcpy(s->ks.wc, desc->world_center, 12);
@@ -1853,6 +1936,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         stats->n_trace_rays = rays_trace;
         stats->n_shadow_launches = n_shadow_launches;
         stats->n_shadow_rays = h_rays[0];
+        stats->queries_decided = h_rays[7];
         stats->trace_node_visits = h_rays[1];
         stats->trace_tri_tests = h_rays[2];
         stats->trace_wave_steps = h_rays[4];

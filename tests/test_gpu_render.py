@@ -44,7 +44,8 @@ def same_seed_check(scene, psamples, hsamples=1, lsamples=1, seed=7, frac=0.995,
     np.testing.assert_allclose(mg, mr_, rtol=5e-4)
     assert st.stack_overflows == 0
     # closest-hit query counts agree to the handful of paths that branch differently
-    assert abs(int(st.rays) - int(o.rays)) <= 1e-3 * o.rays + 16
+    # (probe queries that the kernel answers without a search are the checker's traceFAST calls all the same)
+    assert abs(int(st.rays) + int(st.queries_decided) - int(o.rays)) <= 1e-3 * o.rays + 16
     return fb, ref
 
 
@@ -234,3 +235,22 @@ def test_march_samples_beyond_the_sizing_bound_are_marched_in_slices(monkeypatch
     monkeypatch.delenv("WAPT_PROBE_CAP")
     monkeypatch.delenv("WAPT_SHADOW_CAP")
     same_seed_check(sc, 2, seed=5, frac=0.99)
+
+
+@pytest.mark.parametrize("name", ["fog_sphere", "fog_area", "dragon_milk"])
+def test_probe_rays_aimed_at_their_light_equal_plain_searches(name, monkeypatch):
+    """directLightHit / directLightingSingleScatter probes only ask whether the closest hit is one given light: the
+    kernel tests the light's quad first, searches no further than the quad, and skips rays that miss it (or lights
+    without geometry).  WAPT_GENERAL_PROBE=1 gives every probe the plain closest-hit search: same image up to the
+    order of the float atomics, and the same number of queries (searched + decided)."""
+    sc, spp = {
+        "fog_sphere": (scenes.fog(res=(24, 16), lights="sphere"), 2),
+        "fog_area": (scenes.fog(res=(24, 16), lights="area"), 2),
+        "dragon_milk": (scenes.dragon("milk", res=(32, 18), n_along=120, n_around=40, td=3), 4),
+    }[name]
+    fast, st_fast = gpu_render(sc, spp, seed=3)
+    monkeypatch.setenv("WAPT_GENERAL_PROBE", "1")
+    general, st_gen = gpu_render(sc, spp, seed=3)
+    np.testing.assert_allclose(fast, general, rtol=2e-4, atol=1e-6)
+    assert st_gen.queries_decided == 0 and st_fast.queries_decided > 0
+    assert st_fast.rays + st_fast.queries_decided == st_gen.rays
