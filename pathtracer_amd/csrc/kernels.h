@@ -44,6 +44,7 @@ struct KScene {
     const DMaterial* mats;   // [n_objects + 1], the last one is the global medium
     const DLight* lights;
     int32_t n_lights, n_objects;
+    int32_t has_inside;      // some object's inside scatters (the march kernel's 16-probe branch can be needed)
     int32_t fast_probe;      // probe rays may be aimed at their light's quad (k_probe); 0: plain closest-hit searches
     int32_t fast_shadow;     // shadow walks may be finished from registers (k_shadow); 0: always the general path
     DCamera cam;

@@ -719,7 +719,7 @@ __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScen
             bool child_done = false;  // (uniform over the block: set under block-wide votes only)
             for (int l = 0; l < sc.n_lights; l++) {
                 const DLight& L = sc.lights[l];
-                if (__syncthreads_or(act && !inside)) {
+                {
                     // (i) in the open: light sampling and sphere sampling, MIS-weighted (cpp:487-553)
                     for (int k = 0; k < p.lsamples; k++) {
                         bool emit = false;
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScen
                         child_done = true;
                     }
                 }
-                if (__syncthreads_or(act && inside_ok)) {
+                if (sc.has_inside && __syncthreads_or(act && inside_ok)) {
                     // (ii) inside an object: 16 refracted connections per light (cpp:560-583), three per compaction
                     V3 toL = normalized(ld3(L.centre) - S);
                     for (int k0 = 0; k0 < 16; k0 += 3) {
@@ -1507,6 +1507,7 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     s->ks.lights = (const DLight*)s->d_lights;
     s->ks.n_lights = desc->n_lights;
     s->ks.n_objects = desc->n_objects;
+    s->ks.has_inside = s->has_inside ? 1 : 0;
     // WAPT_GENERAL_SHADOW=1 sends every shadow walk through the step-by-step path (the tests compare the two)
     s->ks.fast_shadow = env_u32("WAPT_GENERAL_SHADOW", 0) ? 0 : 1;
     // WAPT_GENERAL_PROBE=1: every probe ray gets the plain closest-hit search (the tests compare the two)
