@@ -742,13 +742,17 @@ __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScen
                             continue;
                         }
                         // first light sample, the sphere-sampling probe and (with the first light) the child
-                        uint32_t dim = WAPT_DIM_VPROBE + 2u * (uint32_t)(s * sc.n_lights + l);
-                        const V3 pdir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
-                        const V3 pw = (4.0f * WAPT_PI) * cs;
-                        uint32_t* const counters[3] = {&q.cnt[CNT_S], &q.cnt[CNT_P], &q.cnt[CNT_R(depth + 1)]};
-                        // (a light without geometry is never the closest hit of a ray: its probes are not emitted)
-                        const bool probe = act && !inside && finite_dir(pdir) && !is_zero(pw);
+                        // (a light without geometry is never the closest hit of a ray: its probes are not emitted,
+                        //  and their directions - unit vectors, always usable - not even drawn)
                         const bool reachable = !sc.fast_probe || L.ntri != 0;
+                        const V3 pw = (4.0f * WAPT_PI) * cs;
+                        V3 pdir = v3(0.f, 0.f, 1.f);
+                        if (reachable) {
+                            uint32_t dim = WAPT_DIM_VPROBE + 2u * (uint32_t)(s * sc.n_lights + l);
+                            pdir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
+                        }
+                        uint32_t* const counters[3] = {&q.cnt[CNT_S], &q.cnt[CNT_P], &q.cnt[CNT_R(depth + 1)]};
+                        const bool probe = act && !inside && finite_dir(pdir) && !is_zero(pw);
                         if (probe && !reachable) skipped++;
                         const bool preds[3] = {emit, probe && reachable, cemit && !child_done};
                         uint32_t slots[3];
