@@ -831,8 +831,8 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
 //
 // Most walks end in one of three ways that need no second look at the scene, and those are decided
 // from what the search left in registers: (1) the search met an opaque surface clearly before B and
-// stopped there: zero visibility (cpp:778); (2) nothing was hit up to B while the walk is in the clear
-// global medium: full visibility of what is left (cpp:764-772); (3) same medium, and the only hit is
+// stopped there: zero visibility (cpp:778); (2) nothing was hit up to B: the walk arrives, attenuated by the medium
+// it is in over what is left of the way (cpp:764-772; nothing to do in the clear global medium); (3) same medium, and the only hit is
 // the quad of the light that B was sampled on, reached steeply: B lies on that quad, so the hit is B
 // itself to within a fraction of TRACE_BIAS, the walk arrives (cpp:775) and a plain (opaque, clear,
 // non-dielectric) surface changes nothing there.  Everything else - media, transparent surfaces, hits
@@ -898,8 +898,21 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                 const bool in_clear = gclear && cur == global_m;
                 const bool at_target = tri != 0xffffffffu && target != 0u && (t.hflag & WAPT_TRI_PLAIN) &&
                                        (t.hflag >> WAPT_TRI_OBJ_SHIFT) == target - 1u;
-                if (sc.fast_shadow && in_clear && (tri == 0xffffffffu || at_target)) lit = true;  // (2), (3)
-                else general = true;
+                if (sc.fast_shadow && in_clear && (tri == 0xffffffffu || at_target)) {
+                    lit = true;  // (2), (3)
+                } else if (sc.fast_shadow && tri == 0xffffffffu) {
+                    // (2) in a medium that attenuates: what is left of the way to B, through the medium the walk is in
+                    // (the last step of the general path, cpp:764-775)
+                    float seg = ABl;
+                    if (it > 0) {
+                        float4 b = q.SB[task];
+                        seg = mag(v3(b.x, b.y, b.z) - t.o);
+                    }
+                    V = V * attenuation(sc.mats[cur], seg);
+                    lit = true;
+                } else {
+                    general = true;
+                }
             }
             if (general) {
                 const V3 P0 = t.o, ABn = t.d;
