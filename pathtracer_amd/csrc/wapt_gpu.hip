@@ -852,16 +852,20 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
     Trav t = {};
     bool have_task = false, have_ray = false;
     // walk state (names as in the reference).  The segment start P0 and the direction ABn live in t.o / t.d;
-    // B, the weight and the pixel stay in the queue and are read again by the few lanes that need them
-    // (registers decide how many waves fit a SIMD here).
+    // B stays in the queue and is read again by the few walks that pass a transparent surface.
     V3 V = v3(1, 1, 1);
     float ABl = 0.f, d = 0.f;
     int cur = global_m, it = 0;
     uint32_t task = 0, target = 0;
+    V3 cw = v3(0, 0, 0);  // weight and pixel of the task (read with it: a read at the walk's end is a memory round trip
+    uint32_t cpixel = 0;  // that the whole wave waits for, 4 % of the kernel)
     for (;;) {
         uint32_t idx = feed.take(!have_task);
         if (idx != 0xffffffffu) {
             float4 a = q.SA[idx], b = q.SB[idx];
+            float4 w4s = q.SC[idx];
+            cw = v3(w4s.x, w4s.y, w4s.z);
+            cpixel = f2u(a.w);
             V3 A = v3(a.x, a.y, a.z);
             V3 AB = v3(b.x, b.y, b.z) - A;
             ABl = mag(AB);
@@ -974,10 +978,9 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
         V3 contrib = v3(0, 0, 0);
         uint32_t pixel = 0;
         if (lit) {
-            float4 w4 = q.SC[task];
-            pixel = f2u(q.SA[task].w);
-            contrib = v3(w4.x, w4.y, w4.z) * V;
-            DBG(pixel, "shadow task=%u lit V=%g w=%g d=%.6f ABl=%.6f\n", task, V.x, w4.x, d, ABl);
+            pixel = cpixel;
+            contrib = cw * V;
+            DBG(pixel, "shadow task=%u lit V=%g w=%g d=%.6f ABl=%.6f\n", task, V.x, cw.x, d, ABl);
         }
         wave_add_rgb(q.sum, stage, lit, pixel, contrib);
     }
