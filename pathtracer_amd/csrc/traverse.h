@@ -458,19 +458,22 @@ __device__ __forceinline__ uint32_t trace_ray(const TraceMem& m, V3 o, V3 d, flo
 }
 
 // Hands work items to the lanes of one wave of a persistent launch.  The queue is dealt out in groups
-// of 64 consecutive items; group g belongs to shard g % WAPT_FEED_SHARDS, every shard has a counter
+// of 2^gshift consecutive items; group g belongs to shard g % WAPT_FEED_SHARDS, every shard has a counter
 // of its own, and a wave whose current group is used up draws the next group of the shard its block
-// maps to (one returning atomic per 64 items, spread over 32 counters).  The cost of a ray varies by
+// maps to (one returning atomic per group, spread over 32 counters).  The cost of a ray varies by
 // more than 10x (wall vs. mesh): with a fixed share per wave the average wave was resident for 43 % of
 // the kernel's duration, with groups drawn on demand the waves finish together.  Neighbouring groups
 // are in flight at the same time, which keeps the BVH lines they touch in L1/L2.
+// The wave waits for the atomic's answer, so the group grows with the launch (64 items below 2^23, up to
+// 512 from 2^27 on: dragonChrome +2 %, the short shadow rays of the fog scene +20 %), and stays small
+// where the tail of a small launch would otherwise be left to a few waves (dragonMilk: -5 % at 256 throughout).
 // A lane that asks (`want`) gets the next unassigned item or 0xffffffff; take() must be called by all
 // lanes of the wave together, and the counters must be zero when the kernel starts.
 #define WAPT_FEED_SHARDS 32
 #define WAPT_FEED_STRIDE 64
 struct WaveFeed {
     uint32_t next, end;   // unassigned part of the current group
-    uint32_t n, shard;
+    uint32_t n, shard, gshift;
     uint32_t* counter;
     bool dry;
     __device__ __forceinline__ uint32_t take(bool want) {
@@ -480,12 +483,12 @@ struct WaveFeed {
             uint32_t k = 0;
             if (__lane_id() == 0) k = atomicAdd(counter, 1u);
             k = (uint32_t)__shfl((int)k, 0);
-            unsigned long long b = ((unsigned long long)k * WAPT_FEED_SHARDS + shard) * 64ull;
+            unsigned long long b = ((unsigned long long)k * WAPT_FEED_SHARDS + shard) << gshift;
             if (b >= n) {
                 dry = true;
             } else {
                 next = (uint32_t)b;
-                end = (b + 64ull < n) ? (uint32_t)(b + 64ull) : n;
+                end = (uint32_t)min(b + (1ull << gshift), (unsigned long long)n);
             }
         }
         uint32_t lane = __lane_id();
@@ -504,6 +507,7 @@ __device__ __forceinline__ WaveFeed wave_feed(uint32_t n, uint32_t* counters) {
     f.counter = counters + f.shard * WAPT_FEED_STRIDE;  // one 256-byte line per counter: atomics on words of
                                                         // one line queue behind each other like atomics on one word
     f.next = f.end = 0;
+    f.gshift = n >= (1u << 27) ? 9u : n >= (1u << 25) ? 8u : n >= (1u << 23) ? 7u : 6u;
     f.dry = n == 0;
     return f;
 }

@@ -1229,6 +1229,7 @@ struct wapt_scene {
     uint32_t* d_cnt = nullptr;
     unsigned long long* d_rays = nullptr;
     uint32_t* h_cnt = nullptr;  // pinned
+    unsigned long long* h_u64 = nullptr;  // pinned: 16 ray counters + 2 march-sample counts
     KQueues kq;
     void* d_queue_block = nullptr;
     size_t queue_bytes = 0;
@@ -1515,6 +1516,7 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     HIPCHK_S(hipMalloc((void**)&s->d_rays, 16 * sizeof(unsigned long long)));
     HIPCHK_S(hipMemset(s->d_rays, 0, 16 * sizeof(unsigned long long)));
     HIPCHK_S(hipHostMalloc((void**)&s->h_cnt, CNT_TOTAL * sizeof(uint32_t) + 64));
+    HIPCHK_S(hipHostMalloc((void**)&s->h_u64, 18 * sizeof(unsigned long long)));
 
     memset(&s->ks, 0, sizeof(s->ks));
     s->ks.tm.nodes = (const uint4*)s->d_nodes;
@@ -1557,6 +1559,7 @@ extern "C" void wapt_scene_destroy(wapt_scene* s) {
     (void)hipFree(s->d_rays);
     (void)hipFree(s->d_queue_block);
     if (s->h_cnt) (void)hipHostFree(s->h_cnt);
+    if (s->h_u64) (void)hipHostFree(s->h_u64);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1658,7 +1661,12 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
         if (capS > (1u << 20)) capS >>= 1;
         if (capP > (1u << 20)) capP >>= 1;
     }
-    if (s->d_queue_block && s->queue_depths >= depths && s->capR >= capR && s->capS >= capS && s->capP >= capP) return WAPT_OK;
+    // A block that is a little smaller than what this call would get is kept (the call runs in slightly smaller
+    // chunks): the capacities of a scene with media follow the free memory, which moves between calls (memory of
+    // processes that have ended is returned in the background), and hipFree of a block of this size took 0.2-2 s.
+    auto enough = [](uint32_t have, uint32_t want) { return have >= want - want / 4; };
+    if (s->d_queue_block && s->queue_depths >= depths && enough(s->capR, capR) && enough(s->capS, capS) && enough(s->capP, capP))
+        return WAPT_OK;
     if (s->d_queue_block) {
         // keep what an earlier, larger call allocated for the dimensions that do not grow
         capR = std::max(capR, s->capR);
@@ -1869,10 +1877,10 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
             // Scenes with a scattering object: chunk_for() bounds a segment inside an object by the object's box,
             // which an open mesh can exceed.  The exact number of march samples of the step is counted before anything
             // is shaded; a step that would not fit is cut down and traced again.
-            unsigned long long h_m[2] = {0, 0};
+            unsigned long long* h_m = s->h_u64 + 16;  // (a copy into pageable memory goes through the runtime's staging path)
             HIPCHK(hipMemsetAsync(s->d_rays + 14, 0, 2 * sizeof(unsigned long long), st));
             tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_count, vgrid, vblock, 0, st, ks, q, kp, d, start, n, s->d_rays + 14); });
-            HIPCHK(hipMemcpyAsync(h_m, s->d_rays + 14, sizeof(h_m), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h_m, s->d_rays + 14, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             const uint64_t M = h_m[0], kids_surface = (uint64_t)n * (uint64_t)std::max(prm->hsamples, 1);
             const bool fits = M <= s->kq.capQM && (d >= td || kids_surface + M <= s->capR);
@@ -1941,9 +1949,9 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
             have[d + 1] = std::min(s->h_cnt[CNT_R(d + 1)], s->capR);
         }
     }
-    unsigned long long h_rays[16] = {0};
+    unsigned long long* h_rays = s->h_u64;
     HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_rays, s->d_rays, sizeof(h_rays), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_rays, s->d_rays, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     auto t1 = std::chrono::steady_clock::now();
