@@ -341,8 +341,8 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_raygen(KScene sc, KQueues q, KP
     }
 }
 
-// traceFAST for every task of the step (content.cpp:91-123).  Each wave owns a contiguous slice of
-// the step's tasks and streams it through its lanes: a lane whose ray has ended takes the next one.
+// traceFAST for every task of the step (content.cpp:91-123).  The waves draw groups of consecutive tasks
+// on demand (WaveFeed) and stream them through their lanes: a lane whose ray has ended takes the next one.
 // COUNT adds node-visit and triangle-test tallies (rays[1], rays[2]) for the bytes-per-ray figure of
 // the roofline.
 template <bool COUNT>
