@@ -151,6 +151,12 @@ def main():
                            "wave_steps_per_ray_x64": 64.0 * st.shadow_wave_steps / max(st.n_shadow_rays, 1),
                            "node_phase_lane_util": st.shadow_node_visits / max(64.0 * st.shadow_node_steps, 1),
                            "tri_phase_lane_util": st.shadow_tri_tests / max(64.0 * st.shadow_tri_trips, 1)}}
+        if st.n_probe_rays:
+            util["probe"] = {"node_visits_per_ray": st.probe_node_visits / st.n_probe_rays,
+                             "tri_tests_per_ray": st.probe_tri_tests / st.n_probe_rays,
+                             "wave_steps_per_ray_x64": 64.0 * st.probe_wave_steps / st.n_probe_rays,
+                             "node_phase_lane_util": st.probe_node_visits / max(64.0 * st.probe_node_steps, 1),
+                             "tri_phase_lane_util": st.probe_tri_tests / max(64.0 * st.probe_tri_trips, 1)}
         bytes_per_ray = 32 + 8 + info.node_size * nodes_per_ray + info.tri_size * tris_per_ray
         rays_per_launch = n_rays / max(n_launch, 1)
         avg_ms = ms_trace / max(n_launch, 1)
@@ -170,7 +176,7 @@ def main():
                            "tri_tests_per_ray": tris_per_ray, "rays_per_launch": rays_per_launch,
                            "avg_launch_ms": avg_ms, "launches_per_step": int(n_launch),
                            "grays_per_s_in_kernel": rays_per_launch / (avg_ms * 1e-3) / 1e9,
-                           "kernel_ms_per_step": fam, "lane_utilisation": util, "shadow_rays_per_step": int(shadow_rays)}
+                           "kernel_ms_per_step": fam, "lane_utilisation": util, "shadow_rays_per_step": int(shadow_rays), "probe_rays_per_step": int(st.n_probe_rays)}
         if traffic:
             # memory-side rate of the same kernel (PMC passes of the round profile): what HBM / Infinity Cache
             # actually carried, next to the algorithmic rate above

@@ -138,6 +138,10 @@ typedef struct wapt_stats {
      * directLightHit / directLightingSingleScatter probes (cpp:631-687) only ask whether the closest hit is one given
      * light; a ray that misses that light's quad (or a light without geometry) cannot have it */
     uint64_t queries_decided;
+    /* of `rays`: the searches of those two probe estimators (the rest of rays - n_trace_rays are shadow-walk steps) */
+    uint64_t n_probe_rays;
+    /* profile bit 1: the five tallies for the probe searches */
+    uint64_t probe_node_visits, probe_tri_tests, probe_wave_steps, probe_node_steps, probe_tri_trips;
 } wapt_stats;
 
 typedef struct wapt_ray {

@@ -1010,6 +1010,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
 // search stops at the first other triangle it accepts.  A light with no geometry (sphere lights) is never
 // hit, one with another number of triangles gets the plain closest-hit search.  Queries answered without a
 // search are tallied in rays[7], not in the ray count.
+template <bool COUNT>
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     __shared__ union WaveLds {
@@ -1074,7 +1075,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
         if (!__any(have_task)) break;
         bool lit = false;
         V3 contrib = v3(0, 0, 0);
-        bool done = trav_step<false, false, WAPT_COOP>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc, coop);
+        bool done = trav_step<COUNT, false, WAPT_COOP>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc, coop);
         if (have_ray && !done && want != 0xffffffffu && t.hit != 0xffffffffu) {
             // a triangle in front of the quad (or the quad itself, which ends the matter as well)
             const DLight& L = sc.lights[want_light];
@@ -1144,8 +1145,18 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
     }
     rays = wave_sum(rays);
     decided = wave_sum(decided);
-    if (lane_id() == 0 && rays) atomicAdd(q.rays, (unsigned long long)rays);
+    if (lane_id() == 0 && rays) atomicAdd(&q.rays[3], (unsigned long long)rays);
     if (lane_id() == 0 && decided) atomicAdd(&q.rays[7], (unsigned long long)decided);
+    if (COUNT) {
+        uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.tris);
+        if (lane_id() == 0) {
+            atomicAdd(&q.rays[16], (unsigned long long)a);
+            atomicAdd(&q.rays[17], (unsigned long long)b);
+            atomicAdd(&q.rays[18], (unsigned long long)tc.wsteps);
+            atomicAdd(&q.rays[19], (unsigned long long)tc.nsteps);
+            atomicAdd(&q.rays[20], (unsigned long long)tc.ttrips);
+        }
+    }
     if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
 }
 
@@ -1229,7 +1240,7 @@ struct wapt_scene {
     uint32_t* d_cnt = nullptr;
     unsigned long long* d_rays = nullptr;
     uint32_t* h_cnt = nullptr;  // pinned
-    unsigned long long* h_u64 = nullptr;  // pinned: 16 ray counters + 2 march-sample counts
+    unsigned long long* h_u64 = nullptr;  // pinned: 24 ray counters + 2 march-sample counts
     KQueues kq;
     void* d_queue_block = nullptr;
     size_t queue_bytes = 0;
@@ -1513,10 +1524,10 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     s->sgrid = std::max(1u, cus * env_u32("WAPT_SBLOCKS_PER_CU", 2) * (1024u / WAPT_SBLOCK));  // blocks of the shading kernels
     HIPCHK_S(hipMalloc((void**)&s->d_cnt, CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK_S(hipMemset(s->d_cnt, 0, CNT_TOTAL * sizeof(uint32_t)));
-    HIPCHK_S(hipMalloc((void**)&s->d_rays, 16 * sizeof(unsigned long long)));
-    HIPCHK_S(hipMemset(s->d_rays, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK_S(hipMalloc((void**)&s->d_rays, 24 * sizeof(unsigned long long)));
+    HIPCHK_S(hipMemset(s->d_rays, 0, 24 * sizeof(unsigned long long)));
     HIPCHK_S(hipHostMalloc((void**)&s->h_cnt, CNT_TOTAL * sizeof(uint32_t) + 64));
-    HIPCHK_S(hipHostMalloc((void**)&s->h_u64, 18 * sizeof(unsigned long long)));
+    HIPCHK_S(hipHostMalloc((void**)&s->h_u64, 26 * sizeof(unsigned long long)));
 
     memset(&s->ks, 0, sizeof(s->ks));
     s->ks.tm.nodes = (const uint4*)s->d_nodes;
@@ -1837,7 +1848,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     unsigned long long issued = 0;
     uint64_t rays_trace = 0, n_trace_launches = 0, n_shadow_launches = 0;
     bool aborted = false;
-    HIPCHK(hipMemsetAsync(s->d_rays, 0, 16 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(s->d_rays, 0, 24 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_OVERFLOW, 0u);
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_QOVERFLOW, 0u);
 
@@ -1877,7 +1888,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
             // Scenes with a scattering object: chunk_for() bounds a segment inside an object by the object's box,
             // which an open mesh can exceed.  The exact number of march samples of the step is counted before anything
             // is shaded; a step that would not fit is cut down and traced again.
-            unsigned long long* h_m = s->h_u64 + 16;  // (a copy into pageable memory goes through the runtime's staging path)
+            unsigned long long* h_m = s->h_u64 + 24;  // (a copy into pageable memory goes through the runtime's staging path)
             HIPCHK(hipMemsetAsync(s->d_rays + 14, 0, 2 * sizeof(unsigned long long), st));
             tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_count, vgrid, vblock, 0, st, ks, q, kp, d, start, n, s->d_rays + 14); });
             HIPCHK(hipMemcpyAsync(h_m, s->d_rays + 14, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1932,7 +1943,10 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
                     continue;
                 }
                 tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_volume, vgrid, vblock, 0, st, ks, q, kp, d, start, (uint32_t)m0, (uint32_t)ms); });
-                tm.run(FAM_PROBE, [&] { hipLaunchKernelGGL(k_probe, grid, block, 0, st, ks, q); });
+                tm.run(FAM_PROBE, [&] {
+                    if (prm->profile & 2) hipLaunchKernelGGL(k_probe<true>, grid, block, 0, st, ks, q);
+                    else hipLaunchKernelGGL(k_probe<false>, grid, block, 0, st, ks, q);
+                });
                 m0 += ms;
                 if (m0 < M) {
                     run_shadow();
@@ -1951,20 +1965,21 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     }
     unsigned long long* h_rays = s->h_u64;
     HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_rays, s->d_rays, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_rays, s->d_rays, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     auto t1 = std::chrono::steady_clock::now();
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->paths = (uint64_t)W * H * (uint64_t)prm->sample_count;
-        stats->rays = rays_trace + h_rays[0];
+        stats->rays = rays_trace + h_rays[0] + h_rays[3];
         stats->stack_overflows = s->h_cnt[CNT_OVERFLOW] + s->h_cnt[CNT_QOVERFLOW];
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
         stats->n_trace_launches = n_trace_launches;
         stats->n_trace_rays = rays_trace;
         stats->n_shadow_launches = n_shadow_launches;
         stats->n_shadow_rays = h_rays[0];
+        stats->n_probe_rays = h_rays[3];
         stats->queries_decided = h_rays[7];
         stats->trace_node_visits = h_rays[1];
         stats->trace_tri_tests = h_rays[2];
@@ -1976,6 +1991,11 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         stats->shadow_wave_steps = h_rays[10];
         stats->shadow_node_steps = h_rays[11];
         stats->shadow_tri_trips = h_rays[12];
+        stats->probe_node_visits = h_rays[16];
+        stats->probe_tri_tests = h_rays[17];
+        stats->probe_wave_steps = h_rays[18];
+        stats->probe_node_steps = h_rays[19];
+        stats->probe_tri_trips = h_rays[20];
         if (tm.on) {
             double ms[FAM_N] = {0};
             for (auto& r : tm.recs) {
