@@ -107,10 +107,20 @@ WAPT_HD V3 hemisphere_uniform(V3 D, float u1, float u2) {
     return polar(D, cosT, sinT, u2 * 2.0f * WAPT_PI);
 }
 
-// hemisphereSampleUniform(D, maxAngle, ..): uniform in the cone (fundamentals.cpp:429-444)
-WAPT_HD V3 cone_uniform(V3 D, float cosMax, float u1, float u2) {
-    float cosT = 1.0f - u1 * (1.0f - cosMax);
-    float sinT = sqrtf(fmaxf(0.f, 1.0f - cosT * cosT));
+// 1 - cos(asin(s)): the reference evaluates 1.0 - cos(coneAngle) in double (lights.cpp:244, 256); in single
+// precision 1 - sqrt(1 - s^2) loses everything for a small light far away (a point light is a sphere of radius 1:
+// s = 0.002, 1 - cos = 2e-6 against an ulp of 6e-8), so the difference is written without the cancellation.
+WAPT_HD float one_minus_cos_of_asin(float s) {
+    float c = sqrtf(fmaxf(0.f, 1.0f - s * s));
+    return s * s / (1.0f + c);
+}
+
+// hemisphereSampleUniform(D, maxAngle, ..): uniform in the cone (fundamentals.cpp:429-444), given 1 - cos(maxAngle).
+// cos(theta) = 1 - x with x = u1 (1 - cos(maxAngle)), and sin^2(theta) = x (2 - x) keeps a narrow cone's few ulps.
+WAPT_HD V3 cone_uniform(V3 D, float omcMax, float u1, float u2) {
+    float x = u1 * omcMax;
+    float cosT = 1.0f - x;
+    float sinT = sqrtf(fmaxf(0.f, x * (2.0f - x)));
     return polar(D, cosT, sinT, u2 * 2.0f * WAPT_PI);
 }
 
@@ -210,7 +220,8 @@ WAPT_HD bool light_sample(const DLight& L, V3 SP, V3 SN, bool has_normal, float 
     V3 SLn = (1.0f / dist) * SL;
     float sinC = L.radius / dist;
     float cosC = sqrtf(fmaxf(0.f, 1.0f - sinC * sinC));
-    V3 D = cone_uniform(SLn, cosC, u1, u2);
+    float omc = one_minus_cos_of_asin(sinC);
+    V3 D = cone_uniform(SLn, omc, u1, u2);
     if (has_normal && dot(SN, D) <= 0.0f) return false;
     float s1, s2;
     float d;
@@ -219,7 +230,7 @@ WAPT_HD bool light_sample(const DLight& L, V3 SP, V3 SN, bool has_normal, float 
     else
         d = dist * cosC;
     *LP = SP + d * D;
-    *rpdf = 2.0f * WAPT_PI * (1.0f - cosC);
+    *rpdf = 2.0f * WAPT_PI * omc;
     return true;
 }
 
@@ -227,7 +238,5 @@ WAPT_HD bool light_sample(const DLight& L, V3 SP, V3 SN, bool has_normal, float 
 WAPT_HD float light_pdf(const DLight& L, V3 P, V3 SP) {
     if (L.type == 0) return 1.0f / (L.area * area_to_solid_angle(SP, P, ld3(L.N)));
     float dist = mag(P - SP);
-    float sinC = L.radius / dist;
-    float cosC = sqrtf(fmaxf(0.f, 1.0f - sinC * sinC));
-    return 1.0f / (2.0f * WAPT_PI * (1.0f - cosC));
+    return 1.0f / (2.0f * WAPT_PI * one_minus_cos_of_asin(L.radius / dist));
 }

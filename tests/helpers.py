@@ -56,4 +56,5 @@ def rel_rmse(a, b, mask=None):
     b = np.asarray(b, np.float64)
     if mask is not None:
         a, b = a[mask], b[mask]
-    return float(np.sqrt(np.mean((a - b) ** 2)) / np.mean(b))
+    m = float(np.mean(b))
+    return float(np.sqrt(np.mean((a - b) ** 2)) / m) if m else 0.0
