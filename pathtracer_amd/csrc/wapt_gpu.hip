@@ -887,7 +887,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             // refined distance and the reference's thresholds.
             float rest = ABl - d, margin = 0.002f + 1e-4f * ABl;
             trav_begin(t, t.o, t.d, WAPT_TRACE_BIAS, rest + margin);
-            t.tblock = rest - margin;
+            t.tblock = sc.fast_shadow ? rest - margin : -1.0f;  // (the step-by-step path searches for the closest hit)
             have_ray = true;
             rays++;
         }

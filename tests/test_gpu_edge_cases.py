@@ -62,3 +62,45 @@ def test_camera_outside_the_world_sphere_of_a_foggy_scene():
 @pytest.mark.parametrize("res", [(1, 1), (13, 7), (9, 16)])
 def test_image_sizes_off_the_tile_grid(res):
     same_seed_check(scenes.cornell(res=res, spheres=False), 8)
+
+
+def sphere(centre, radius, seg=(10, 20)):
+    v, f = meshes.uv_sphere(centre, radius, *seg)
+    return meshes.expand(v, f)
+
+
+@pytest.mark.parametrize("ior", [1.0, 0.8, 2.4])
+def test_dielectrics_with_unusual_indices(ior):
+    """Only a dielectric with ior > 1 stops a shadow walk (cpp:757-759); through the others the walk goes on, surface by
+    surface.  At ior <= 1 the Fresnel term of some events is exactly zero, and so is the weight of everything below the
+    reflected branch: the reference still walks to the lights from there, the kernel does not emit a shadow walk whose
+    weight is zero - same image and same path rays, fewer shadow rays (0.15 % here), so the query counts are compared
+    for ior 2.4 only."""
+    sc = box_scene([area_light(**scenes.LIGHT)], res=(28, 28), extra=[sphere((275, 200, 275), 130)],
+                   extra_mats=[material("dielectric", ior=ior)], td=5)
+    same_seed_check(sc, 8, frac=0.99, count_rays=ior > 1.0)
+
+
+def test_the_parsers_flagless_sss_material_and_a_scattering_object_that_does_not_scatter():
+    # "g sss" never raises a surface flag (myRenderer.cpp:573-598): paths end on it; a dielectricsss object with
+    # ss = 0 only absorbs
+    sss = material("sss", ior=1.3, sa=(0.001, 0.002, 0.003), ss=(0.01, 0.01, 0.01))
+    dead_milk = material("dielectricsss", ior=1.3, kt=(1, 1, 1), sa=(0.002, 0.004, 0.008), ss=(0, 0, 0))
+    sc = box_scene([area_light(**scenes.LIGHT)], res=(28, 28), extra=[sphere((160, 120, 300), 110), sphere((400, 120, 250), 110)],
+                   extra_mats=[sss, dead_milk], td=4)
+    same_seed_check(sc, 8, frac=0.99)
+
+
+def test_glass_overlapping_milk_in_fog_with_several_samples_per_event():
+    milk = material("dielectricsss", **scenes.MILK)
+    sc = box_scene([area_light(**scenes.LIGHT), sphere_light((120, 300, 420), 20.0, (800000, 500000, 200000))],
+                   res=(16, 12), extra=[sphere((230, 150, 275), 120), sphere((340, 150, 275), 120)],
+                   extra_mats=[material("dielectric", ior=1.5), milk],
+                   global_medium=material("medium", **scenes.FOG), td=3, mr=0.01)
+    same_seed_check(sc, 2, hsamples=2, lsamples=2, frac=0.98)
+
+
+def test_dense_fog_high_march_rate_and_steep_exponential_march():
+    dense = material("medium", ss=(0.004, 0.006, 0.008), sa=(0.002, 0.001, 0.0005))
+    sc = box_scene([area_light(**scenes.LIGHT)], res=(14, 10), global_medium=dense, td=2, mr=0.05, me=0.004)
+    same_seed_check(sc, 2, frac=0.98)

@@ -29,7 +29,7 @@ def gpu_render(scene, psamples, hsamples=1, lsamples=1, seed=0, **kw):
         c.close()
 
 
-def same_seed_check(scene, psamples, hsamples=1, lsamples=1, seed=7, frac=0.995, **kw):
+def same_seed_check(scene, psamples, hsamples=1, lsamples=1, seed=7, frac=0.995, count_rays=True, **kw):
     fb, st = gpu_render(scene, psamples, hsamples, lsamples, seed, **kw)
     o = oracle_api.OracleScene(scene)
     ref = o.render(psamples, hsamples, lsamples, seed=seed, threads=16,
@@ -45,7 +45,8 @@ def same_seed_check(scene, psamples, hsamples=1, lsamples=1, seed=7, frac=0.995,
     assert st.stack_overflows == 0
     # closest-hit query counts agree to the handful of paths that branch differently
     # (probe queries that the kernel answers without a search are the checker's traceFAST calls all the same)
-    assert abs(int(st.rays) + int(st.queries_decided) - int(o.rays)) <= 1e-3 * o.rays + 16
+    if count_rays:
+        assert abs(int(st.rays) + int(st.queries_decided) - int(o.rays)) <= 1e-3 * o.rays + 16
     return fb, ref
 
 
