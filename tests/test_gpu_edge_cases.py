@@ -104,3 +104,31 @@ def test_dense_fog_high_march_rate_and_steep_exponential_march():
     dense = material("medium", ss=(0.004, 0.006, 0.008), sa=(0.002, 0.001, 0.0005))
     sc = box_scene([area_light(**scenes.LIGHT)], res=(14, 10), global_medium=dense, td=2, mr=0.05, me=0.004)
     same_seed_check(sc, 2, frac=0.98)
+
+
+def test_many_lights_several_hemisphere_and_light_samples():
+    lights = [area_light(**scenes.LIGHT)]
+    for k in range(6):
+        a = 2.0 * np.pi * k / 6
+        lights.append(sphere_light((275 + 200 * np.cos(a), 80 + 60 * k, 275 + 200 * np.sin(a)), 6.0 + 5 * k,
+                                   (150000 * (1 + k % 3), 150000 * (1 + (k + 1) % 3), 150000 * (1 + (k + 2) % 3))))
+    sc = box_scene(lights, res=(20, 20), extra=[sphere((275, 120, 275), 110)], extra_mats=[material("diffuse", (0.6, 0.6, 0.6))], td=2)
+    same_seed_check(sc, 4, hsamples=3, lsamples=2)
+
+
+@pytest.mark.parametrize("scale", [0.01, 4.0])
+def test_the_scene_at_other_scales(scale):
+    """Everything but TRACE_BIAS scales: the box 5.5 or 2 200 units wide.  The reference's bias of 0.001 is absolute and
+    its hit points are single precision, so a larger scene pushes the bias below the rounding of the coordinates and
+    which rays re-hit the surface they start on becomes a matter of the last bit on either side: measured 99.3 % of
+    the pixels within tolerance at 4x, 98.96 % at 8x, 85 % at 30x (image means still within 0.2 %)."""
+    base = scenes.cornell(res=(24, 24), spheres=True, sphere_segments=(10, 20))
+    L = scenes.LIGHT
+    light = area_light(P=tuple(scale * x for x in L["P"]), U=tuple(scale * x for x in L["U"]), V=tuple(scale * x for x in L["V"]),
+                       power=tuple(scale * scale * x for x in L["power"]))
+    from pathtracer_amd.scene import camera
+    cam = camera(P=(275 * scale, 275 * scale, -755 * scale), at=(275 * scale, 275 * scale, 0), up=(0, 1, 0), fov=40.0, res=(24, 24), width=1.0)
+    n_l = len(base.lights)
+    ms = [base.tri_verts[base.tri_obj == n_l + g] * np.float32(scale) for g in range(len(base.materials) - n_l)]
+    sc = Scene(cam, [light], base.materials[n_l:], ms, world_center=tuple(275.0 * scale for _ in range(3)), world_radius=1100.0 * scale, td=3)
+    same_seed_check(sc, 8, frac=0.99)
