@@ -78,3 +78,34 @@ def test_single_triangle_and_misses(content_mod):
     np.testing.assert_allclose(h["t"][[0, 5]], [5.0, 5.0], rtol=1e-6)
     np.testing.assert_allclose(h["t"][[1, 2]], [1e7, 1e7])
     np.testing.assert_allclose(h["Ng"][0], [0, 0, 1])
+
+
+def test_unusual_rays_end_as_misses_or_agree_with_the_checker(content_mod):
+    """Rays a caller should not send but may: non-finite or zero directions, an empty (tnear, tfar] interval, a
+    negative tnear, un-normalised and axis-parallel directions.  None may hang the traversal; the non-finite and the
+    empty ones miss, the rest agree with the checker."""
+    sc = scenes.cornell(res=(16, 16), spheres=True, sphere_segments=(8, 16))
+    nan, inf = np.nan, np.inf
+    odd = np.array([[275, 275, 275, 0.001, nan, 0, 1, 1e7],
+                    [275, 275, 275, 0.001, 0, inf, 0, 1e7],
+                    [nan, 275, 275, 0.001, 0, 0, 1, 1e7],
+                    [275, 275, 275, 0.001, 0, 0, 0, 1e7],
+                    [275, 275, 275, 5.0, 0, 0, 1, 1.0],
+                    [275, 275, 275, 0.001, 0, 0, 1, nan]], np.float32)
+    fine = np.array([[275, 275, 275, -10.0, 0, 0, 1, 1e7],
+                     [275, 275, 275, 0.001, 0, 0, 250, 1e7],      # un-normalised: t is in units of |dir|
+                     [275, 275, 275, 0.001, 0, 1e-3, 0, 1e7],
+                     [275, 275, -100, 0.001, 0, 0, 1, 1e7],
+                     [10, 200, 300, 0.001, 1, 0, 0, 1e7],         # (off the walls' diagonals: a hit on one is a tie)
+                     [300, 540, 200, 0.001, 0, -1, 0, 1e7],
+                     [275, 275, 275, 0.001, 1, 1, 1, 1e7]], np.float32)
+    c = content_mod.wa_content(sc)
+    try:
+        h_odd = c.traceFAST(odd)
+        h = c.traceFAST(fine)
+    finally:
+        c.close()
+    assert (h_odd["prim"] == -1).all() and (h_odd["obj"] == -1).all()
+    want = oracle_api.OracleScene(sc).intersect(fine, threads=2)
+    assert (h["prim"] == want["prim"]).all() and (h["obj"] == want["obj"]).all()
+    np.testing.assert_allclose(h["t"], want["t"], rtol=1e-5)
