@@ -9,6 +9,10 @@
 
 #include "rng.h"
 
+#ifndef WAPT_HW_SINCOS
+#define WAPT_HW_SINCOS 1
+#endif
+
 #define WAPT_PI 3.1415926535f          // M_PI as the reference defines it, src/fundamentals.h:12
 #define WAPT_TRACE_BIAS 0.001f         // TRACE_BIAS, src/unidirectionalPathTracer.cpp:13
 #define WAPT_TFAR 10000000.0f          // tfar of every query, src/content.cpp:95
@@ -32,6 +36,8 @@ WAPT_HD V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x 
 WAPT_HD float mag(V3 a) { return sqrtf(dot(a, a)); }
 WAPT_HD V3 normalized(V3 a) {
     float m = mag(a);
+    // (three divisions, as the reference: one reciprocal and three products is 2.4 % of the frame faster, and moves
+    //  directions by an ulp, which is enough to lower the same-seed agreement with the CPU checker from 99.74 to 99.52 %)
     return V3{a.x / m, a.y / m, a.z / m};
 }
 WAPT_HD bool is_zero(V3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
@@ -92,11 +98,23 @@ WAPT_HD void frame(V3 D, V3* ta, V3* tb) {
     *tb = normalized(cross(a, D));
 }
 
-WAPT_HD V3 polar(V3 D, float cosT, float sinT, float phi) {
+// sine and cosine of 2 pi u, u in [0, 1): the hardware's sine and cosine take their argument in turns and are good
+// to about 1e-6 here; the same-seed agreement with the CPU checker is the same with them as with sincosf, scene by
+// scene, and the surface kernel is 3 % faster.
+WAPT_HD void sincos_turns(float u, float* s, float* c) {
+#if defined(__HIP_DEVICE_COMPILE__) && WAPT_HW_SINCOS
+    *s = __builtin_amdgcn_sinf(u);
+    *c = __builtin_amdgcn_cosf(u);
+#else
+    sincosf(u * 2.0f * WAPT_PI, s, c);
+#endif
+}
+
+WAPT_HD V3 polar(V3 D, float cosT, float sinT, float turns) {
     V3 ta, tb;
     frame(D, &ta, &tb);
     float s, c;
-    sincosf(phi, &s, &c);
+    sincos_turns(turns, &s, &c);
     return cosT * D + sinT * (c * ta + s * tb);
 }
 
@@ -104,7 +122,7 @@ WAPT_HD V3 polar(V3 D, float cosT, float sinT, float phi) {
 WAPT_HD V3 hemisphere_uniform(V3 D, float u1, float u2) {
     float cosT = 1.0f - u1;
     float sinT = sqrtf(fmaxf(0.f, 1.0f - cosT * cosT));
-    return polar(D, cosT, sinT, u2 * 2.0f * WAPT_PI);
+    return polar(D, cosT, sinT, u2);
 }
 
 // 1 - cos(asin(s)): the reference evaluates 1.0 - cos(coneAngle) in double (lights.cpp:244, 256); in single
@@ -121,7 +139,7 @@ WAPT_HD V3 cone_uniform(V3 D, float omcMax, float u1, float u2) {
     float x = u1 * omcMax;
     float cosT = 1.0f - x;
     float sinT = sqrtf(fmaxf(0.f, x * (2.0f - x)));
-    return polar(D, cosT, sinT, u2 * 2.0f * WAPT_PI);
+    return polar(D, cosT, sinT, u2);
 }
 
 // sphereSampleUniform(): polar axis y (fundamentals.cpp:556-566)
@@ -129,18 +147,17 @@ WAPT_HD V3 sphere_uniform(float u1, float u2) {
     float cosT = 1.0f - 2.0f * u1;
     float sinT = sqrtf(fmaxf(0.f, 1.0f - cosT * cosT));
     float s, c;
-    sincosf(u2 * 2.0f * WAPT_PI, &s, &c);
+    sincos_turns(u2, &s, &c);
     return v3(sinT * c, cosT, sinT * s);
 }
 
 // sphereSampleBiased3(D, a, &rpdf) (fundamentals.cpp:501-523); u1 drives phi, u2 theta.
 WAPT_HD V3 sphere_biased3(V3 D, float a, float u1, float u2, float* rpdf) {
     const float hp = 0.5f * WAPT_PI;
-    float phi = u1 * 2.0f * WAPT_PI;
     float theta = hp - powf(powf(hp, a + 1.0f) * u2, 1.0f / (a + 1.0f));
     float sinT = sinf(theta), cosT = cosf(theta);
     *rpdf = 1.0f / (((a + 1.0f) / (4.0f * powf(hp, a + 2.0f))) * powf(hp - theta, a) / sinT);
-    return polar(D, cosT, sinT, phi);
+    return polar(D, cosT, sinT, u1);
 }
 
 // solveQuadraticEquation (fundamentals.cpp:569-578)
