@@ -36,9 +36,26 @@ WAPT_HD V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x 
 WAPT_HD float mag(V3 a) { return sqrtf(dot(a, a)); }
 WAPT_HD V3 normalized(V3 a) {
     float m = mag(a);
-    // (three divisions, as the reference: one reciprocal and three products is 2.4 % of the frame faster, and moves
-    //  directions by an ulp, which is enough to lower the same-seed agreement with the CPU checker from 99.74 to 99.52 %)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Three divisions by the same length, as the reference has them, and rounded as a division rounds: one refined
+    // reciprocal for all three, then per component the steps of the hardware's division sequence (product, two
+    // corrections from the exact residual) without its range scaling - the divisor is a length of scene scale.
+    // 18 instructions instead of 30: the surface kernel is 4 % faster, the same-seed agreement with the CPU checker
+    // is unchanged scene by scene.  (One reciprocal and three plain products would be cheaper still and move the
+    // directions by an ulp: that alone lowered the agreement from 99.74 to 99.52 %.)
+    float r = __builtin_amdgcn_rcpf(m);
+    r = fmaf(fmaf(-m, r, 1.0f), r, r);
+    float qx = a.x * r, qy = a.y * r, qz = a.z * r;
+    qx = fmaf(fmaf(-qx, m, a.x), r, qx);
+    qy = fmaf(fmaf(-qy, m, a.y), r, qy);
+    qz = fmaf(fmaf(-qz, m, a.z), r, qz);
+    qx = fmaf(fmaf(-qx, m, a.x), r, qx);
+    qy = fmaf(fmaf(-qy, m, a.y), r, qy);
+    qz = fmaf(fmaf(-qz, m, a.z), r, qz);
+    return V3{qx, qy, qz};
+#else
     return V3{a.x / m, a.y / m, a.z / m};
+#endif
 }
 WAPT_HD bool is_zero(V3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
 WAPT_HD V3 vexp(V3 a) { return V3{expf(a.x), expf(a.y), expf(a.z)}; }
