@@ -33,7 +33,23 @@ WAPT_HD V3 operator*(V3 a, float s) { return V3{s * a.x, s * a.y, s * a.z}; }
 WAPT_HD V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 WAPT_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 WAPT_HD V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-WAPT_HD float mag(V3 a) { return sqrtf(dot(a, a)); }
+// Correctly rounded square root of a value that is zero or of ordinary magnitude (lengths, sines, discriminants of
+// scene-scale quantities): the hardware's estimate moved by one ulp where its exact residual says so - the
+// correction steps of the compiler's sqrtf sequence without its rescaling of denormal arguments (9 instructions
+// instead of 16).  Zero, infinity and NaN come out as sqrtf gives them.
+WAPT_HD float wsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const uint32_t b = __float_as_uint(s);
+    const float dn = __uint_as_float(b - 1u), up = __uint_as_float(b + 1u);
+    float r = (0.0f >= fmaf(-dn, s, x)) ? dn : s;
+    r = (0.0f < fmaf(-up, s, x)) ? up : r;
+    return r;
+#else
+    return sqrtf(x);
+#endif
+}
+WAPT_HD float mag(V3 a) { return wsqrt(dot(a, a)); }
 WAPT_HD V3 normalized(V3 a) {
     float m = mag(a);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -138,7 +154,7 @@ WAPT_HD V3 polar(V3 D, float cosT, float sinT, float turns) {
 // hemisphereSampleUniform(D, &rpdf): cos(theta) = 1 - u1, rpdf = 2 pi (fundamentals.cpp:408-425)
 WAPT_HD V3 hemisphere_uniform(V3 D, float u1, float u2) {
     float cosT = 1.0f - u1;
-    float sinT = sqrtf(fmaxf(0.f, 1.0f - cosT * cosT));
+    float sinT = wsqrt(fmaxf(0.f, 1.0f - cosT * cosT));
     return polar(D, cosT, sinT, u2);
 }
 
@@ -146,7 +162,7 @@ WAPT_HD V3 hemisphere_uniform(V3 D, float u1, float u2) {
 // precision 1 - sqrt(1 - s^2) loses everything for a small light far away (a point light is a sphere of radius 1:
 // s = 0.002, 1 - cos = 2e-6 against an ulp of 6e-8), so the difference is written without the cancellation.
 WAPT_HD float one_minus_cos_of_asin(float s) {
-    float c = sqrtf(fmaxf(0.f, 1.0f - s * s));
+    float c = wsqrt(fmaxf(0.f, 1.0f - s * s));
     return s * s / (1.0f + c);
 }
 
@@ -155,14 +171,14 @@ WAPT_HD float one_minus_cos_of_asin(float s) {
 WAPT_HD V3 cone_uniform(V3 D, float omcMax, float u1, float u2) {
     float x = u1 * omcMax;
     float cosT = 1.0f - x;
-    float sinT = sqrtf(fmaxf(0.f, x * (2.0f - x)));
+    float sinT = wsqrt(fmaxf(0.f, x * (2.0f - x)));
     return polar(D, cosT, sinT, u2);
 }
 
 // sphereSampleUniform(): polar axis y (fundamentals.cpp:556-566)
 WAPT_HD V3 sphere_uniform(float u1, float u2) {
     float cosT = 1.0f - 2.0f * u1;
-    float sinT = sqrtf(fmaxf(0.f, 1.0f - cosT * cosT));
+    float sinT = wsqrt(fmaxf(0.f, 1.0f - cosT * cosT));
     float s, c;
     sincos_turns(u2, &s, &c);
     return v3(sinT * c, cosT, sinT * s);
@@ -181,7 +197,7 @@ WAPT_HD V3 sphere_biased3(V3 D, float a, float u1, float u2, float* rpdf) {
 WAPT_HD bool solve_quadratic(float a, float b, float c, float* s1, float* s2) {
     float disc = b * b - 4.0f * a * c;
     if (disc < 0.f) return false;
-    float r = sqrtf(disc);
+    float r = wsqrt(disc);
     *s1 = (-b + r) / (2.0f * a);
     *s2 = (-b - r) / (2.0f * a);
     return true;
@@ -199,11 +215,11 @@ WAPT_HD V3 refract_dir(V3 Ng, V3 D, float ior, float* fresnel) {
     float tm = mag(tv);
     V3 tangent = tm > 0.f ? (1.0f / tm) * tv : v3(0.f, 0.f, 0.f);
     float c1 = NdotD;
-    float s1 = sqrtf(fmaxf(0.f, 1.0f - NdotD * NdotD));
+    float s1 = wsqrt(fmaxf(0.f, 1.0f - NdotD * NdotD));
     float f;
     if (NdotD > 0.0f) {
         float s2 = s1 / ior;
-        float c2 = sqrtf(1.0f - s2 * s2);
+        float c2 = wsqrt(1.0f - s2 * s2);
         float a = (ior * c1 - c2) / (ior * c1 + c2);
         float b = (c1 - ior * c2) / (c1 + ior * c2);
         f = 0.5f * (a * a + b * b);
@@ -216,7 +232,7 @@ WAPT_HD V3 refract_dir(V3 Ng, V3 D, float ior, float* fresnel) {
         *fresnel = 1.0f;
         return v3(0.f, 0.f, 0.f);
     }
-    float c2 = sqrtf(1.0f - s2 * s2);
+    float c2 = wsqrt(1.0f - s2 * s2);
     c1 = -c1;
     float a = (c1 - ior * c2) / (c1 + ior * c2);
     float b = (ior * -c2) / (ior * c1 + c2);
@@ -253,7 +269,7 @@ WAPT_HD bool light_sample(const DLight& L, V3 SP, V3 SN, bool has_normal, float 
     if (dist < L.radius + WAPT_TRACE_BIAS) return false;
     V3 SLn = (1.0f / dist) * SL;
     float sinC = L.radius / dist;
-    float cosC = sqrtf(fmaxf(0.f, 1.0f - sinC * sinC));
+    float cosC = wsqrt(fmaxf(0.f, 1.0f - sinC * sinC));
     float omc = one_minus_cos_of_asin(sinC);
     V3 D = cone_uniform(SLn, omc, u1, u2);
     if (has_normal && dot(SN, D) <= 0.0f) return false;
