@@ -15,7 +15,11 @@
  *  - plain C types only; every pointer is a host pointer unless the name
  *    starts with d_ (device pointer on the scene's GPU);
  *  - every function returns 0 on success, a WAPT_E_* code otherwise, and
- *    never lets a C++ exception out; wapt_last_error() gives the text;
+ *    never lets a C++ exception out; wapt_last_error() gives the text of
+ *    the calling thread's last failure;
+ *  - a wapt_scene owns its stream, queues and counters: calls on ONE scene
+ *    must not overlap (wapt_progressive_abort excepted); different scenes,
+ *    on the same or on different GPUs, may be used from different threads;
  *  - framebuffers are linear, un-tone-mapped mean radiance, float RGB,
  *    row-major, fb[(j*W+i)*3+c], row j=0 = bottom of the picture, exactly
  *    what udp_renderer::render leaves in the caller's buffer
