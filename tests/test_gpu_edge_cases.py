@@ -132,3 +132,30 @@ def test_the_scene_at_other_scales(scale):
     ms = [base.tri_verts[base.tri_obj == n_l + g] * np.float32(scale) for g in range(len(base.materials) - n_l)]
     sc = Scene(cam, [light], base.materials[n_l:], ms, world_center=tuple(275.0 * scale for _ in range(3)), world_radius=1100.0 * scale, td=3)
     same_seed_check(sc, 8, frac=0.99)
+
+
+def test_two_scenes_rendered_from_two_threads_at_once():
+    """Scenes own their stream, queues and counters: two of them on one GPU, driven from two threads at the same time,
+    give what each gives alone."""
+    import threading
+    from pathtracer_amd import renderer
+    scs = [scenes.cornell(res=(64, 64), spheres=True, sphere_segments=(12, 24)), scenes.fog(res=(32, 24), lights="sphere")]
+    spp = [16, 2]
+    alone = [gpu_render(sc, n, seed=9)[0] for sc, n in zip(scs, spp)]
+    contents = [renderer.wa_content(sc) for sc in scs]
+    out, err = [None, None], []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                out[k] = renderer.udp_renderer(contents[k], spp[k], 1, 1, 1, seed=9).render()
+        except Exception as e:  # surfaces in the main thread below
+            err.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    [c.close() for c in contents]
+    assert not err, err
+    for a, b in zip(alone, out):
+        np.testing.assert_allclose(b, a, rtol=2e-4, atol=1e-6)
