@@ -50,14 +50,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # WAPT_BENCH_REHEARSAL=1: the multi-rank control flow on a box with ONE GPU - every rank renders on cuda:0 and the
+    # collectives go through host copies over gloo (the numbers mean nothing; the sequence of collectives is the same)
+    rehearsal = world > 1 and os.environ.get("WAPT_BENCH_REHEARSAL", "0") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    def reduce_sum_to_rank0(x):
+        if rehearsal:
+            h = x.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            x.copy_(h)
+        else:
+            dist.reduce(x, dst=0, op=dist.ReduceOp.SUM)
 
     from pathtracer_amd import renderer, scenes
     W, H = (int(x) for x in args.res.lower().split("x"))
@@ -84,8 +100,8 @@ def main():
         acc.zero_()
         torch.cuda.synchronize()
         st = r.render_accumulate(acc.data_ptr(), rank * spp, spp, profile=profile)
-        if world > 1:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
+        if world > 1 and profile == 0:  # (the profiled frames below run on rank 0 alone: no collective there)
+            reduce_sum_to_rank0(acc)
         if rank == 0:
             torch.mul(acc, 1.0 / total_spp, out=image)
         return st
@@ -106,7 +122,7 @@ def main():
         rays += st.rays
     fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt, float(rays)], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, float(rays)], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

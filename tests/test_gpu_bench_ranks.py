@@ -1,0 +1,29 @@
+"""bench.py's multi-rank control flow on a box with one GPU: two ranks under torch.distributed.run, both rendering on
+cuda:0, the collectives over gloo through host copies (WAPT_BENCH_REHEARSAL=1).  The sequence of collectives is the one
+the RCCL run issues - warm-up and timed frames with their reduce, the barrier-fenced timing, the max/sum all-reduces,
+rank 0's profiled frames WITHOUT a collective, the closing barrier - so a rank that issues one the others do not
+shows up here as a hang (the timeout) instead of on the 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_run_the_whole_bench_and_rank0_prints_one_line():
+    env = dict(os.environ, WAPT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--spp", "4", "--res", "256x144", "--scene", "cornell"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=240)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "8 spp image" in d["config"]["workload"] and "roofline" in d and d["roofline"]["frac"] > 0
+    assert "cpu_baseline" not in d  # rank 0 at N=1 only
