@@ -1634,7 +1634,7 @@ FanOut fan_out(const wapt_scene* s, const wapt_render_params* prm, int d) {
 // closest-hit kernel were busy 55 % of the time, at 2^26 90 %; whole frame, dragonChrome 1080p: 2^26 2931,
 // 2^27 3023, 2^28 3055 Mpaths/s), and HBM is plentiful, so the default is 2^28 tasks per depth (12 GiB per
 // depth) and 2^29 shadow / probe tasks (24 GiB each) for scenes with media, whose chunks are sized by the
-// worst-case fan-out of a marched segment; all of it is cut down to what the call can use and to a quarter
+// worst-case fan-out of a marched segment; all of it is cut down to what the call can use and to a quarter (half without media)
 // of the free device memory.
 int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task, uint64_t shadows_per_task, uint64_t probes_per_task) {
     int depths = td + 1;
@@ -1648,7 +1648,10 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
     uint32_t capP = env_u32("WAPT_PROBE_CAP", s->has_scatter ? (1u << 29) : 64u);
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t budget = (uint64_t)(free_b + s->queue_bytes) / 4;
+    // scenes with media take what they are given (their fan-out is bounded by the budget only): a quarter; the others
+    // need at most 68 GB for td 3, which a quarter of an otherwise empty 288 GB just covers - half, so that a few GB
+    // held by someone else do not halve the launches
+    const uint64_t budget = (uint64_t)(free_b + s->queue_bytes) / (s->has_scatter ? 4 : 2);
     if (s->has_scatter) {
         // A launch of c tasks of depth 0 needs c x kids slots in R[1], c x shadows in S and c x probes in P (and
         // the deeper launches less): the budget goes to the queues in these proportions, which gives the largest
