@@ -1632,13 +1632,14 @@ FanOut fan_out(const wapt_scene* s, const wapt_render_params* prm, int d) {
 // Capacities: large launches matter more than anything else for the traversal kernels (a launch ends
 // with a tail in which most lanes have run out of work: at 2^22 tasks per launch the lanes of the
 // closest-hit kernel were busy 55 % of the time, at 2^26 90 %; whole frame, dragonChrome 1080p: 2^26 2931,
-// 2^27 3023, 2^28 3055 Mpaths/s), and HBM is plentiful, so the default is 2^28 tasks per depth (12 GiB per
-// depth) and 2^29 shadow / probe tasks (24 GiB each) for scenes with media, whose chunks are sized by the
+// 2^27 3023, 2^28 3055 Mpaths/s; later kernels: 2^28 3400, 2^29 - the 256-spp frame in one piece - 3520), and HBM is
+// plentiful, so the default is 2^29 tasks per depth (24 GiB per depth, 135 GB with the shadow queue and the hit
+// records at td 3) and 2^29 shadow / probe tasks for scenes with media, whose chunks are sized by the
 // worst-case fan-out of a marched segment; all of it is cut down to what the call can use and to a quarter (half without media)
 // of the free device memory.
 int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task, uint64_t shadows_per_task, uint64_t probes_per_task) {
     int depths = td + 1;
-    uint32_t capR = env_u32("WAPT_RAD_CAP", 1u << 28);
+    uint32_t capR = env_u32("WAPT_RAD_CAP", 1u << 29);
     // (a marched segment emits one child per march sample: the deeper queues of a scene with media fill up
     //  from far fewer paths than they have slots)
     capR = (uint32_t)std::min<uint64_t>(capR, ((paths + 4095) & ~(uint64_t)4095) * std::max<uint64_t>(kids_per_task, 1));
@@ -1649,8 +1650,7 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // scenes with media take what they are given (their fan-out is bounded by the budget only): a quarter; the others
-    // need at most 68 GB for td 3, which a quarter of an otherwise empty 288 GB just covers - half, so that a few GB
-    // held by someone else do not halve the launches
+    // need 135 GB for a 1080p frame of 256 spp at td 3 in one piece: half
     const uint64_t budget = (uint64_t)(free_b + s->queue_bytes) / (s->has_scatter ? 4 : 2);
     if (s->has_scatter) {
         // A launch of c tasks of depth 0 needs c x kids slots in R[1], c x shadows in S and c x probes in P (and
