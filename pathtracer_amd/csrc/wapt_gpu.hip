@@ -1635,7 +1635,7 @@ FanOut fan_out(const wapt_scene* s, const wapt_render_params* prm, int d) {
 // 2^27 3023, 2^28 3055 Mpaths/s; later kernels: 2^28 3400, 2^29 - the 256-spp frame in one piece - 3520), and HBM is
 // plentiful, so the default is 2^29 tasks per depth (24 GiB per depth, 135 GB with the shadow queue and the hit
 // records at td 3) and 2^29 shadow / probe tasks for scenes with media, whose chunks are sized by the
-// worst-case fan-out of a marched segment; all of it is cut down to what the call can use and to a quarter (half without media)
+// worst-case fan-out of a marched segment; all of it is cut down to what the call can use and to a quarter (five eighths without media)
 // of the free device memory.
 int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task, uint64_t shadows_per_task, uint64_t probes_per_task) {
     int depths = td + 1;
@@ -1650,8 +1650,10 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     // scenes with media take what they are given (their fan-out is bounded by the budget only): a quarter; the others
-    // need 135 GB for a 1080p frame of 256 spp at td 3 in one piece: half
-    const uint64_t budget = (uint64_t)(free_b + s->queue_bytes) / (s->has_scatter ? 4 : 2);
+    // need 135 GB for a 1080p frame of 256 spp at td 3 in one piece: five eighths (178 GB of an empty GPU, so that
+    // memory held by others - a process that has just ended, say - does not halve the launches at once)
+    const uint64_t avail = (uint64_t)(free_b + s->queue_bytes);
+    const uint64_t budget = s->has_scatter ? avail / 4 : avail / 8 * 5;
     if (s->has_scatter) {
         // A launch of c tasks of depth 0 needs c x kids slots in R[1], c x shadows in S and c x probes in P (and
         // the deeper launches less): the budget goes to the queues in these proportions, which gives the largest
