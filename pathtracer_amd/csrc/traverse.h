@@ -498,6 +498,10 @@ struct WaveFeed {
         next = (end - next < c) ? end : next + c;
         return got;
     }
+    // Nothing left to hand out, now or later (the same in all lanes of the wave).  A kernel whose lanes can finish
+    // an item at the moment they take it must not leave its loop on "no lane holds an item" alone: the rest of
+    // the wave's current group would be lost.
+    __device__ __forceinline__ bool exhausted() const { return dry && next >= end; }
 };
 
 __device__ __forceinline__ WaveFeed wave_feed(uint32_t n, uint32_t* counters) {

@@ -891,7 +891,9 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             have_ray = true;
             rays++;
         }
-        if (!__any(have_task)) break;
+        // (a round whose tasks were all finished on the spot is no reason to leave while the feed has more; the
+        //  rest of the loop body does nothing then)
+        if (!__any(have_task) && feed.exhausted()) break;
         bool lit = false;
         if (trav_step<COUNT, true>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
             have_ray = false;
@@ -1072,7 +1074,9 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
                 rays++;
             }
         }
-        if (!__any(have_task)) break;
+        // (a round whose tasks were all finished on the spot is no reason to leave while the feed has more; the
+        //  rest of the loop body does nothing then)
+        if (!__any(have_task) && feed.exhausted()) break;
         bool lit = false;
         V3 contrib = v3(0, 0, 0);
         bool done = trav_step<COUNT, false, WAPT_COOP>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc, coop);
@@ -1635,7 +1639,7 @@ FanOut fan_out(const wapt_scene* s, const wapt_render_params* prm, int d) {
 // 2^27 3023, 2^28 3055 Mpaths/s; later kernels: 2^28 3400, 2^29 - the 256-spp frame in one piece - 3520), and HBM is
 // plentiful, so the default is 2^29 tasks per depth (24 GiB per depth, 135 GB with the shadow queue and the hit
 // records at td 3) and 2^29 shadow / probe tasks for scenes with media, whose chunks are sized by the
-// worst-case fan-out of a marched segment; all of it is cut down to what the call can use and to a quarter (five eighths without media)
+// worst-case fan-out of a marched segment; all of it is cut down to what the call can use and to five eighths
 // of the free device memory.
 int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task, uint64_t shadows_per_task, uint64_t probes_per_task) {
     int depths = td + 1;
@@ -1649,11 +1653,12 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
     uint32_t capP = env_u32("WAPT_PROBE_CAP", s->has_scatter ? (1u << 29) : 64u);
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    // scenes with media take what they are given (their fan-out is bounded by the budget only): a quarter; the others
-    // need 135 GB for a 1080p frame of 256 spp at td 3 in one piece: five eighths (178 GB of an empty GPU, so that
-    // memory held by others - a process that has just ended, say - does not halve the launches at once)
+    // Five eighths of what is free (178 GB of an empty GPU).  Scenes without media need 135 GB for a 1080p frame of
+    // 256 spp at td 3 in one piece and should not lose that to a few GB held by others (a process that has just
+    // ended, say); scenes with media take what they are given, their fan-out is bounded by the budget only (fog,
+    // 8 spp: 11.9 Mpaths/s with a quarter, 12.5 with five eighths; dragonMilk 323 -> 343).
     const uint64_t avail = (uint64_t)(free_b + s->queue_bytes);
-    const uint64_t budget = s->has_scatter ? avail / 4 : avail / 8 * 5;
+    const uint64_t budget = avail / 8 * 5;
     if (s->has_scatter) {
         // A launch of c tasks of depth 0 needs c x kids slots in R[1], c x shadows in S and c x probes in P (and
         // the deeper launches less): the budget goes to the queues in these proportions, which gives the largest
@@ -1662,7 +1667,9 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
         const uint64_t kids = std::max<uint64_t>(kids_per_task, 1), sh = std::max<uint64_t>(shadows_per_task, 1),
                        pr = std::max<uint64_t>(probes_per_task, 1);
         const uint64_t per_task = (uint64_t)depths * kids * 48 + sh * 48 + pr * 56 + 12 * kids;
-        uint64_t c = std::min<uint64_t>((paths + 4095) & ~(uint64_t)4095, budget / per_task);
+        // (not more than the call can use: its paths x kids tasks is what the second level can hold at most - the
+        //  launches of the deeper levels, where most of the work of a low-spp frame is, grow with c too)
+        uint64_t c = std::min<uint64_t>(((paths + 4095) & ~(uint64_t)4095) * kids, budget / per_task);
         c = std::max<uint64_t>(c, 4096);
         auto cap32 = [](uint64_t v) { return (uint32_t)std::min<uint64_t>(v, 0xfffff000u); };
         capR = std::min(capR, cap32(c * kids)) & ~63u;
