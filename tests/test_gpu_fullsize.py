@@ -75,3 +75,43 @@ def test_full_size_mean_and_rays_per_path_match_checker(content):
     rpp_ref = o.rays / (160 * 90 * 64.0)
     print("rays/path gpu", rpp_gpu, "checker", rpp_ref)
     assert abs(rpp_gpu - rpp_ref) <= 0.01 * rpp_ref
+
+
+@pytest.mark.parametrize("name", ["dragon_milk", "fog_area"])
+def test_full_size_media_scenes_do_not_depend_on_shortcuts_or_queue_size(name, monkeypatch):
+    """The scenes with media at 1080p, where single launches carry 10^7..10^8 probe and shadow tasks (the work feed
+    hands out groups of up to 512 there): the frame with the kernels' shortcuts - probes aimed at their light and
+    decided without a search, shadow walks ended from registers - against the frame with plain searches and
+    step-by-step walks, and against the frame rendered through queues a fraction of the size.  Same image up to the
+    order of the float additions, same number of closest-hit queries."""
+    import torch
+
+    def frame(spp):
+        sc = scenes.dragon("milk", res=(W, H)) if name == "dragon_milk" else scenes.fog(res=(W, H), lights="area")
+        c = renderer.wa_content(sc)
+        try:
+            r = renderer.udp_renderer(c, spp, 1, 1, 1, seed=13)
+            acc = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda:0")
+            st = r.render_accumulate(acc.data_ptr(), 0, spp)
+            torch.cuda.synchronize()
+            assert st.stack_overflows == 0
+            return (acc / spp).cpu().numpy().reshape(H, W, 3), int(st.rays) + int(st.queries_decided), int(st.queries_decided)
+        finally:
+            c.close()
+
+    spp = 2 if name == "dragon_milk" else 1
+    fast, q_fast, decided = frame(spp)
+    assert np.isfinite(fast).all() and decided > 0
+    monkeypatch.setenv("WAPT_GENERAL_PROBE", "1")
+    monkeypatch.setenv("WAPT_GENERAL_SHADOW", "1")
+    plain, q_plain, decided_plain = frame(spp)
+    assert decided_plain == 0 and q_plain == q_fast
+    # (per pixel: a handful of samples whose sums arrive in another order; 2e-3 of the pixel's value)
+    np.testing.assert_allclose(fast, plain, rtol=2e-3, atol=1e-5)
+    monkeypatch.delenv("WAPT_GENERAL_PROBE")
+    monkeypatch.delenv("WAPT_GENERAL_SHADOW")
+    monkeypatch.setenv("WAPT_SHADOW_CAP", str(1 << 22))
+    monkeypatch.setenv("WAPT_PROBE_CAP", str(1 << 22))
+    small, q_small, _ = frame(spp)
+    assert q_small == q_fast
+    np.testing.assert_allclose(small, fast, rtol=2e-3, atol=1e-5)
