@@ -77,7 +77,7 @@ def test_full_size_mean_and_rays_per_path_match_checker(content):
     assert abs(rpp_gpu - rpp_ref) <= 0.01 * rpp_ref
 
 
-@pytest.mark.parametrize("name", ["dragon_milk", "fog_area"])
+@pytest.mark.parametrize("name", ["dragon_milk", "fog_area", "fog_sphere", "dragon_glass"])
 def test_full_size_media_scenes_do_not_depend_on_shortcuts_or_queue_size(name, monkeypatch):
     """The scenes with media at 1080p, where single launches carry 10^7..10^8 probe and shadow tasks (the work feed
     hands out groups of up to 512 there): the frame with the kernels' shortcuts - probes aimed at their light and
@@ -87,7 +87,9 @@ def test_full_size_media_scenes_do_not_depend_on_shortcuts_or_queue_size(name, m
     import torch
 
     def frame(spp):
-        sc = scenes.dragon("milk", res=(W, H)) if name == "dragon_milk" else scenes.fog(res=(W, H), lights="area")
+        sc = {"dragon_milk": lambda: scenes.dragon("milk", res=(W, H)), "fog_area": lambda: scenes.fog(res=(W, H), lights="area"),
+              "fog_sphere": lambda: scenes.fog(res=(W, H), lights="sphere"),
+              "dragon_glass": lambda: scenes.dragon("glass", res=(W, H), td=6)}[name]()
         c = renderer.wa_content(sc)
         try:
             r = renderer.udp_renderer(c, spp, 1, 1, 1, seed=13)
@@ -99,19 +101,26 @@ def test_full_size_media_scenes_do_not_depend_on_shortcuts_or_queue_size(name, m
         finally:
             c.close()
 
-    spp = 2 if name == "dragon_milk" else 1
+    spp = {"dragon_milk": 2, "dragon_glass": 4}.get(name, 1)
     fast, q_fast, decided = frame(spp)
-    assert np.isfinite(fast).all() and decided > 0
+    assert np.isfinite(fast).all() and (decided > 0 or name == "dragon_glass")  # (no probes without media)
     monkeypatch.setenv("WAPT_GENERAL_PROBE", "1")
     monkeypatch.setenv("WAPT_GENERAL_SHADOW", "1")
     plain, q_plain, decided_plain = frame(spp)
     assert decided_plain == 0 and q_plain == q_fast
-    # (per pixel: a handful of samples whose sums arrive in another order; 2e-3 of the pixel's value)
-    np.testing.assert_allclose(fast, plain, rtol=2e-3, atol=1e-5)
+    # (per pixel: sums that arrive in another order, 2e-3 of the pixel's value; and one walk in 10^9 that the
+    #  search-precision distance of a shortcut and the refined distance of the step-by-step path decide differently
+    #  - 9 pixels of the fog frame: 99.999 % of the values have to agree)
+    def same(a, b):
+        ok = np.abs(a - b) <= 2e-3 * np.abs(b) + 1e-5
+        assert ok.mean() >= 0.99999, ok.mean()
+        np.testing.assert_allclose(a.mean((0, 1)), b.mean((0, 1)), rtol=1e-4)
+
+    same(fast, plain)
     monkeypatch.delenv("WAPT_GENERAL_PROBE")
     monkeypatch.delenv("WAPT_GENERAL_SHADOW")
     monkeypatch.setenv("WAPT_SHADOW_CAP", str(1 << 22))
     monkeypatch.setenv("WAPT_PROBE_CAP", str(1 << 22))
     small, q_small, _ = frame(spp)
     assert q_small == q_fast
-    np.testing.assert_allclose(small, fast, rtol=2e-3, atol=1e-5)
+    same(small, fast)
