@@ -150,7 +150,9 @@ def test_stress_scene_at_4k_shortcuts_against_plain_paths(monkeypatch):
     monkeypatch.setenv("WAPT_GENERAL_PROBE", "1")
     monkeypatch.setenv("WAPT_GENERAL_SHADOW", "1")
     plain, q_plain = frame()
-    assert q_plain == q_fast
+    # (the device builder's tree is not the same from run to run - its atomics order the nodes - and a ray through an
+    #  edge shared by two objects may meet either: one query more or less in 5e7 was seen)
+    assert abs(q_plain - q_fast) <= 16
     ok = np.abs(fast - plain) <= 2e-3 * np.abs(plain) + 1e-5
     assert ok.mean() >= 0.99999, ok.mean()
     np.testing.assert_allclose(fast.mean((0, 1)), plain.mean((0, 1)), rtol=1e-4)
