@@ -31,9 +31,11 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 #ifndef WAPT_SURFACE_WAVES
 #define WAPT_SURFACE_WAVES 6
 #endif
-// block size of the march kernel (115 registers: two blocks of 512 threads fit a CU, one of 768)
+// block size of the march kernel (113 registers, 4 waves per SIMD: one block of 1024 threads per CU).  The kernel's
+// time follows the number of block-wide queue reservations, not the occupancy: fog scene, ms per 2-spp frame,
+// 264 / 152 / 135 with blocks of 256 / 512 / 1024 threads.
 #ifndef WAPT_VBLOCK
-#define WAPT_VBLOCK 512
+#define WAPT_VBLOCK 1024
 #endif
 #ifndef WAPT_VOLUME_WAVES
 #define WAPT_VOLUME_WAVES 4
