@@ -91,6 +91,20 @@ def main():
     content = renderer.wa_content(sc, device=dev.index)
     build_s = time.time() - t0
     info = content.bvh_info()
+    # The work queues are sized by the free device memory at the first frame.  Memory of a process that has just ended
+    # on this GPU (a test run before the benchmark, say) comes back over a few seconds: wait until it has, so that the
+    # warm-up frame allocates what the timed frames will use.
+    free_prev, stable = -1, 0
+    t_wait = time.time()
+    while time.time() - t_wait < 20.0:
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        if free_b >= 0.9 * total_b:
+            break
+        stable = stable + 1 if free_b == free_prev else 0
+        if stable >= 4:
+            break
+        free_prev = free_b
+        time.sleep(0.5)
     spp, total_spp = args.spp, args.spp * world
     r = renderer.udp_renderer(content, psamples=total_spp, hsamples=1, lsamples=1, seed=2026)
     acc = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
