@@ -369,7 +369,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene s
         }
         if (!__any(have)) break;
         if (trav_step<COUNT, false, WAPT_COOP>(sc.tm, t, have, &s_stack[threadIdx.x], glane, tc, coop)) {
-            q.hits[cur] = make_uint2(f2u(t.tmax), t.hit);  // fp32 distance; k_head refines it
+            q.hits[cur] = make_uint2(f2u(t.tmax), t.hit);  // fp32 distance; k_surface refines it
             have = false;
         }
     }
