@@ -127,7 +127,9 @@ typedef struct wapt_stats {
     uint64_t rays;            /* closest-hit queries (every traceFAST equivalent) */
     uint64_t stack_overflows; /* traversal-stack pushes dropped (must be 0)      */
     double seconds;           /* wall time of the render() equivalent            */
-    /* filled when profile=1: per kernel family, HIP-event milliseconds and launches */
+    /* filled when profile=1: per kernel family, HIP-event milliseconds and launches
+     * (ms_head stays 0: the hit-record pass it timed is part of the surface kernel, ms_shade; ms_volume covers
+     * the march kernel and the two small kernels that count and list its samples) */
     double ms_raygen, ms_trace, ms_head, ms_shade, ms_volume, ms_shadow, ms_probe;
     uint64_t n_trace_launches, n_trace_rays;
     uint64_t n_shadow_launches, n_shadow_rays;
