@@ -405,7 +405,10 @@ __device__ __forceinline__ bool segment_marched(const KScene& sc, const HitCtx& 
 // The kernel moves 48 B of task, 8 B of hit and 48 B of triangle in and 48 B per child or shadow task
 // out and is bound by that traffic, not by arithmetic: the materials share one kernel (lanes of a wave
 // may run different branches) so that nothing is read twice.
+// ONE: one hemisphere and one light sample per event (the reference's defaults): the sample loops are gone.
+template <bool ONE>
 __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
+    const int lsamples = ONE ? 1 : p.lsamples, hsamples = ONE ? 1 : p.hsamples;
     enum { NONE, LAMBERT, MIRROR, DIELECTRIC };
     GRID_LOOP(i, n) {
         const bool valid = i < n;
@@ -484,14 +487,14 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
         }
         const bool lambert = kind == LAMBERT;
         // Lambert, next event estimation: one shadow walk per light sample
-        float rls = 1.0f / (float)p.lsamples;
+        float rls = 1.0f / (float)lsamples;
         for (int l = 0; l < sc.n_lights; l++) {
-            for (int s = 0; s < p.lsamples; s++) {
+            for (int s = 0; s < lsamples; s++) {
                 bool emit = false;
                 V3 LP = v3(0, 0, 0), wt = v3(0, 0, 0);
                 uint32_t tgt = 0u;
                 if (lambert) {
-                    uint32_t dim = WAPT_DIM_NEE + 2u * (uint32_t)(l * p.lsamples + s);
+                    uint32_t dim = WAPT_DIM_NEE + 2u * (uint32_t)(l * lsamples + s);
                     float rpdf;
                     const DLight& L = sc.lights[l];
                     if (light_sample(L, c.P, N1f, true, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &LP, &rpdf)) {
@@ -512,8 +515,8 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
         // children: hsamples uniform hemisphere directions of a Lambert event (no emission at the next
         // hit), or the single continuation of a mirror / dielectric event
         const bool deeper = lambert && (depth + 1 <= p.td);
-        float rhs = 1.0f / (float)p.hsamples;
-        for (int s = 0; s < p.hsamples; s++) {
+        float rhs = 1.0f / (float)hsamples;
+        for (int s = 0; s < hsamples; s++) {
             bool emit = cemit && s == 0;
             V3 dir = cdir, b = cb;
             uint32_t info = cinfo, key = ckey;
@@ -1922,7 +1925,10 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         }
         rays_trace += n;
         n_trace_launches++;
-        tm.run(FAM_SHADE, [&] { hipLaunchKernelGGL(k_surface, sgrid, sblock, 0, st, ks, q, kp, d, start, n); });
+        tm.run(FAM_SHADE, [&] {
+            if (prm->lsamples == 1 && prm->hsamples == 1) hipLaunchKernelGGL(k_surface<true>, sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+            else hipLaunchKernelGGL(k_surface<false>, sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+        });
         auto run_shadow = [&] {
             tm.run(FAM_SHADOW, [&] {
                 if (prm->profile & 2) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, st, ks, q);

@@ -11,6 +11,7 @@ d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]); r=d.get("roofli
 print(sys.argv[1], "Mpaths/s %.1f"%d["value"], "trace_ms %.4f"%r.get("avg_launch_ms",0), {k:round(v,1) for k,v in r.get("kernel_ms_per_step",{}).items()}, r.get("lane_utilisation"))
 PY
 }
+run warmup A=1 > /dev/null || exit 1   # (the first process on a fresh box measures 1-3 % low: not compared)
 run base A=1 || exit 1
 for f in pathtracer_amd/variants/libwapt_*.so; do
   n=$(basename $f .so); n=${n#libwapt_}
