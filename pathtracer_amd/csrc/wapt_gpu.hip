@@ -406,7 +406,8 @@ __device__ __forceinline__ bool segment_marched(const KScene& sc, const HitCtx& 
 // out and is bound by that traffic, not by arithmetic: the materials share one kernel (lanes of a wave
 // may run different branches) so that nothing is read twice.
 // ONE: one hemisphere and one light sample per event (the reference's defaults): the sample loops are gone.
-template <bool ONE>
+// MEDIA: the scene has a participating medium (hit records are kept and marched segments listed for the march kernel).
+template <bool ONE, bool MEDIA>
 __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
     const int lsamples = ONE ? 1 : p.lsamples, hsamples = ONE ? 1 : p.hsamples;
     enum { NONE, LAMBERT, MIRROR, DIELECTRIC };
@@ -428,12 +429,12 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                 // here, where every lane has a hit to refine (the march kernel reads it back from the queue)
                 float tr = refine_distance(sc.tm.tris, h.y, c.o, c.dir, WAPT_TRACE_BIAS, u2f(h.x));
                 h.x = f2u(tr);
-                if (p.write_hits) q.hits[i] = h;
+                if (MEDIA) q.hits[i] = h;
             }
             set_hit(sc, h, c);
             DBG(c.pixel, "head d=%d key=%08x o=(%.6f %.6f %.6f) dir=(%.7f %.7f %.7f) t=%.6f tri=%u P=(%.6f %.6f %.6f) obj=%d beta=%g\n", depth, c.key, c.o.x, c.o.y, c.o.z, c.dir.x, c.dir.y, c.dir.z, c.t, c.tri, c.P.x, c.P.y, c.P.z, c.obj, c.beta.x);
             if (c.tri == 0xffffffffu) {
-                toV = segment_marched(sc, c);
+                if (MEDIA) toV = segment_marched(sc, c);
             } else {
                 const DMaterial& m = sc.mats[c.obj];
                 float xs = wapt_rand(c.stream, WAPT_DIM_SURF);
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                     else if (m.flags & WAPT_MAT_SPECULAR) kind = MIRROR;
                     else if (m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) kind = DIELECTRIC;
                 }
-                toV = segment_marched(sc, c);
+                if (MEDIA) toV = segment_marched(sc, c);
                 N1f = c.entering ? c.N : -c.N;
                 if (kind == LAMBERT) {
                     kd = ld3(m.kd);
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
             }
             push_radiance(q, depth + 1, emit, c.P, dir, b, c.pixel, info, key);
         }
-        if (p.write_hits) {
+        if (MEDIA) {
             uint32_t sv = block_push(&q.cnt[CNT_QV], toV);
             if (toV) q.QV[sv] = i;
         }
@@ -1926,8 +1927,11 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         rays_trace += n;
         n_trace_launches++;
         tm.run(FAM_SHADE, [&] {
-            if (prm->lsamples == 1 && prm->hsamples == 1) hipLaunchKernelGGL(k_surface<true>, sgrid, sblock, 0, st, ks, q, kp, d, start, n);
-            else hipLaunchKernelGGL(k_surface<false>, sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+            const bool one = prm->lsamples == 1 && prm->hsamples == 1;
+            if (one && !kp.write_hits) hipLaunchKernelGGL((k_surface<true, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+            else if (one) hipLaunchKernelGGL((k_surface<true, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+            else if (!kp.write_hits) hipLaunchKernelGGL((k_surface<false, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+            else hipLaunchKernelGGL((k_surface<false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
         });
         auto run_shadow = [&] {
             tm.run(FAM_SHADOW, [&] {
