@@ -843,7 +843,10 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
 // itself to within a fraction of TRACE_BIAS, the walk arrives (cpp:775) and a plain (opaque, clear,
 // non-dielectric) surface changes nothing there.  Everything else - media, transparent surfaces, hits
 // within the search margin of B - takes the general path below, which follows the reference step by step.
-template <bool COUNT>
+// PLAIN: every object of the scene is opaque, clear inside and no dielectric, and the global medium is clear.  A walk
+// is then over with its first search - nothing is passed through, nothing attenuates: blocked if the search stopped
+// at a surface before B or its closest hit lies before B - TRACE_BIAS, arrived otherwise (cpp:764-778 with V = 1).
+template <bool COUNT, bool PLAIN>
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     __shared__ float4 s_stage[WAPT_BLOCK];
@@ -906,7 +909,21 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             const uint32_t tri = t.hit;
             bool blocked = sc.fast_shadow && t.tblock < 0.f;  // (1)
             bool general = false;
-            if (!blocked) {
+            if (PLAIN) {
+                if (!blocked) {
+                    const bool at_target = tri != 0xffffffffu && target != 0u && (t.hflag >> WAPT_TRI_OBJ_SHIFT) == target - 1u;
+                    if (tri == 0xffffffffu || at_target) {
+                        lit = true;  // (2), (3)
+                    } else {
+                        // the distances as the step-by-step path takes them: fp64 for a hit before or near B
+                        float tmax = t.tmax;
+                        if (!(tmax > ABl + (0.002f + 5e-5f * ABl))) tmax = refine_distance(sc.tm.tris, tri, t.o, t.d, WAPT_TRACE_BIAS, tmax);
+                        const float dd = mag(point_at(t.o, tmax, t.d) - t.o);
+                        lit = dd >= ABl - WAPT_TRACE_BIAS;
+                        blocked = !lit;
+                    }
+                }
+            } else if (!blocked) {
                 const bool in_clear = gclear && cur == global_m;
                 const bool at_target = tri != 0xffffffffu && target != 0u && (t.hflag & WAPT_TRI_PLAIN) &&
                                        (t.hflag >> WAPT_TRI_OBJ_SHIFT) == target - 1u;
@@ -1249,6 +1266,7 @@ struct wapt_scene {
     void *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_spill = nullptr;
     uint32_t* d_cnt = nullptr;
     unsigned long long* d_rays = nullptr;
+    bool all_plain = false;
     uint32_t* h_cnt = nullptr;  // pinned
     unsigned long long* h_u64 = nullptr;  // pinned: 24 ray counters + 2 march-sample counts
     KQueues kq;
@@ -1553,6 +1571,10 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     s->ks.has_inside = s->has_inside ? 1 : 0;
     // WAPT_GENERAL_SHADOW=1 sends every shadow walk through the step-by-step path (the tests compare the two)
     s->ks.fast_shadow = env_u32("WAPT_GENERAL_SHADOW", 0) ? 0 : 1;
+    // every object opaque, clear and no dielectric, the global medium clear: the one-search shadow kernel
+    s->all_plain = s->ks.fast_shadow != 0 && (desc->global_medium.flags & WAPT_MAT_CLEAR) != 0;
+    for (int i = 0; i < desc->n_objects; i++)
+        if (!(tri_flags_of(desc->materials[i].flags) & WAPT_TRI_PLAIN)) s->all_plain = false;
     // WAPT_GENERAL_PROBE=1: every probe ray gets the plain closest-hit search (the tests compare the two)
     s->ks.fast_probe = env_u32("WAPT_GENERAL_PROBE", 0) ? 0 : 1;
     s->ks.cam = to_device(desc->camera);
@@ -1935,8 +1957,13 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         });
         auto run_shadow = [&] {
             tm.run(FAM_SHADOW, [&] {
-                if (prm->profile & 2) hipLaunchKernelGGL(k_shadow<true>, grid, block, 0, st, ks, q);
-                else hipLaunchKernelGGL(k_shadow<false>, grid, block, 0, st, ks, q);
+                if (s->all_plain) {
+                    if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, ks, q);
+                    else hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, ks, q);
+                } else {
+                    if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, ks, q);
+                    else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, ks, q);
+                }
             });
         };
         if (s->has_scatter) {
