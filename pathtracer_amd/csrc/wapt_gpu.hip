@@ -666,6 +666,8 @@ __global__ __launch_bounds__(WAPT_VBLOCK) void k_expand(KScene sc, KQueues q, KP
 }
 
 // volumeScattering (cpp:429-621): one march sample of the segment of one task per lane
+// INSIDE: some object's inside scatters (the 16-probe branch below can be needed)
+template <bool INSIDE>
 __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t m0, uint32_t n) {
     uint32_t skipped = 0;  // probes decided here (tallied like those k_probe decides)
     GRID_LOOP(j, n) {
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScen
                         child_done = true;
                     }
                 }
-                if (sc.has_inside && __syncthreads_or(act && inside_ok)) {
+                if (INSIDE && __syncthreads_or(act && inside_ok)) {
                     // (ii) inside an object: 16 refracted connections per light (cpp:560-583), three per compaction
                     V3 toL = normalized(ld3(L.centre) - S);
                     for (int k0 = 0; k0 < 16; k0 += 3) {
@@ -1993,7 +1995,10 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
                     s_used = 0;
                     continue;
                 }
-                tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_volume, vgrid, vblock, 0, st, ks, q, kp, d, start, (uint32_t)m0, (uint32_t)ms); });
+                tm.run(FAM_VOLUME, [&] {
+                    if (s->has_inside) hipLaunchKernelGGL(k_volume<true>, vgrid, vblock, 0, st, ks, q, kp, d, start, (uint32_t)m0, (uint32_t)ms);
+                    else hipLaunchKernelGGL(k_volume<false>, vgrid, vblock, 0, st, ks, q, kp, d, start, (uint32_t)m0, (uint32_t)ms);
+                });
                 tm.run(FAM_PROBE, [&] {
                     if (prm->profile & 2) hipLaunchKernelGGL(k_probe<true>, grid, block, 0, st, ks, q);
                     else hipLaunchKernelGGL(k_probe<false>, grid, block, 0, st, ks, q);
