@@ -848,7 +848,7 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
 // PLAIN: every object of the scene is opaque, clear inside and no dielectric, and the global medium is clear.  A walk
 // is then over with its first search - nothing is passed through, nothing attenuates: blocked if the search stopped
 // at a surface before B or its closest hit lies before B - TRACE_BIAS, arrived otherwise (cpp:764-778 with V = 1).
-template <bool COUNT, bool PLAIN>
+template <bool COUNT, bool PLAIN, bool FOGGY = false>
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     __shared__ float4 s_stage[WAPT_BLOCK];
@@ -914,7 +914,10 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             if (PLAIN) {
                 if (!blocked) {
                     const bool at_target = tri != 0xffffffffu && target != 0u && (t.hflag >> WAPT_TRI_OBJ_SHIFT) == target - 1u;
-                    if (tri == 0xffffffffu || at_target) {
+                    // FOGGY (the global medium attenuates): the part of the way it attenuates - all of it unless the walk
+                    // ends on a back face, whose last stretch the step-by-step path takes through the object's clear inside
+                    float seg = ABl;
+                    if (tri == 0xffffffffu || (!FOGGY && at_target)) {
                         lit = true;  // (2), (3)
                     } else {
                         // the distances as the step-by-step path takes them: fp64 for a hit before or near B
@@ -923,7 +926,13 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                         const float dd = mag(point_at(t.o, tmax, t.d) - t.o);
                         lit = dd >= ABl - WAPT_TRACE_BIAS;
                         blocked = !lit;
+                        if (FOGGY && lit && dd <= ABl + WAPT_TRACE_BIAS) {
+                            int obj, prim;
+                            const V3 N = tri_normal(sc.tm.tris, tri, &obj, &prim);
+                            seg = dot(t.d, N) < 0.0f ? dd : 0.0f;
+                        }
                     }
+                    if (FOGGY && lit && seg > 0.0f) V = attenuation(sc.mats[global_m], seg);
                 }
             } else if (!blocked) {
                 const bool in_clear = gclear && cur == global_m;
@@ -1268,7 +1277,7 @@ struct wapt_scene {
     void *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_spill = nullptr;
     uint32_t* d_cnt = nullptr;
     unsigned long long* d_rays = nullptr;
-    bool all_plain = false;
+    bool all_plain = false, all_plain_foggy = false;
     uint32_t* h_cnt = nullptr;  // pinned
     unsigned long long* h_u64 = nullptr;  // pinned: 24 ray counters + 2 march-sample counts
     KQueues kq;
@@ -1575,8 +1584,9 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     s->ks.fast_shadow = env_u32("WAPT_GENERAL_SHADOW", 0) ? 0 : 1;
     // every object opaque, clear and no dielectric, the global medium clear: the one-search shadow kernel
     s->all_plain = s->ks.fast_shadow != 0 && (desc->global_medium.flags & WAPT_MAT_CLEAR) != 0;
+    s->all_plain_foggy = s->ks.fast_shadow != 0 && (desc->global_medium.flags & WAPT_MAT_CLEAR) == 0;  // the same under a medium
     for (int i = 0; i < desc->n_objects; i++)
-        if (!(tri_flags_of(desc->materials[i].flags) & WAPT_TRI_PLAIN)) s->all_plain = false;
+        if (!(tri_flags_of(desc->materials[i].flags) & WAPT_TRI_PLAIN)) s->all_plain = s->all_plain_foggy = false;
     // WAPT_GENERAL_PROBE=1: every probe ray gets the plain closest-hit search (the tests compare the two)
     s->ks.fast_probe = env_u32("WAPT_GENERAL_PROBE", 0) ? 0 : 1;
     s->ks.cam = to_device(desc->camera);
@@ -1962,6 +1972,9 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
                 if (s->all_plain) {
                     if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, ks, q);
                     else hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, ks, q);
+                } else if (s->all_plain_foggy) {
+                    if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, true, true>), grid, block, 0, st, ks, q);
+                    else hipLaunchKernelGGL((k_shadow<false, true, true>), grid, block, 0, st, ks, q);
                 } else {
                     if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, ks, q);
                     else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, ks, q);
