@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <sstream>
 
 #include "wapt_internal.h"
@@ -155,6 +156,14 @@ bool wapt_read_fast(const std::string& path, std::vector<float>& verts, std::vec
         return false;
     }
     size_t nv = (size_t)hdr[0], nt = (size_t)hdr[1];
+    // the counts come from the file: compare them with its size before anything is sized by them
+    in.seekg(0, std::ios::end);
+    const long long file_bytes = (long long)in.tellg();
+    in.seekg(8, std::ios::beg);
+    if (file_bytes < 0 || (unsigned long long)file_bytes < 8ull + 16ull * nv + 12ull * nt) {
+        err = "truncated .fast file " + path;
+        return false;
+    }
     std::vector<float> v4(nv * 4);
     tris.resize(nt * 3);
     in.read((char*)v4.data(), (std::streamsize)(nv * 16));
@@ -238,7 +247,7 @@ bool wapt_read_obj(const std::string& path, std::vector<float>& verts, std::vect
     return true;
 }
 
-extern "C" int wapt_convert_obj_to_fast(const char* obj_path, const char* fast_path) {
+static int convert_obj_to_fast(const char* obj_path, const char* fast_path) {
     if (!obj_path || !fast_path) return wapt_fail(WAPT_E_INVALID, "null path");
     std::vector<float> v;
     std::vector<int32_t> t;
@@ -256,9 +265,13 @@ extern "C" int wapt_convert_obj_to_fast(const char* obj_path, const char* fast_p
     return of ? WAPT_OK : wapt_fail(WAPT_E_IO, std::string("write failed: ") + fast_path);
 }
 
+extern "C" int wapt_convert_obj_to_fast(const char* obj_path, const char* fast_path) {
+    return wapt_guarded([&] { return convert_obj_to_fast(obj_path, fast_path); });
+}
+
 // ---------------------------------------------------------------- .waff
 
-extern "C" int wapt_waff_load(const char* path, wapt_waff** out) {
+static int waff_load(const char* path, wapt_waff** out) {
     if (!path || !out) return wapt_fail(WAPT_E_INVALID, "null argument");
     *out = nullptr;
     std::ifstream in(path, std::ios::binary);
@@ -267,11 +280,8 @@ extern "C" int wapt_waff_load(const char* path, wapt_waff** out) {
     ss << in.rdbuf();
     Cursor c;
     c.s = ss.str();
-    auto w = new wapt_waff();
-    auto fail = [&](const std::string& m) {
-        delete w;
-        return wapt_fail(WAPT_E_IO, std::string(path) + ": " + m);
-    };
+    std::unique_ptr<wapt_waff> w(new wapt_waff());
+    auto fail = [&](const std::string& m) { return wapt_fail(WAPT_E_IO, std::string(path) + ": " + m); };
 
     // camera block: everything up to the first 'v' is skipped (myRenderer.cpp:325-340)
     int ch;
@@ -525,8 +535,12 @@ extern "C" int wapt_waff_load(const char* path, wapt_waff** out) {
             w->tri_prim.push_back((int32_t)i);
         }
     }
-    *out = w;
+    *out = w.release();
     return WAPT_OK;
+}
+
+extern "C" int wapt_waff_load(const char* path, wapt_waff** out) {
+    return wapt_guarded([&] { return waff_load(path, out); });
 }
 
 extern "C" int wapt_waff_desc(const wapt_waff* w, wapt_scene_desc* d) {
@@ -572,7 +586,7 @@ extern "C" int wapt_tonemap(float* fb, int32_t w, int32_t h) {
     return WAPT_OK;
 }
 
-extern "C" int wapt_write_bmp(const char* path, int32_t w, int32_t h, const float* px) {
+static int write_bmp(const char* path, int32_t w, int32_t h, const float* px) {
     if (!path || !px || w <= 0 || h <= 0) return wapt_fail(WAPT_E_INVALID, "bad image");
     size_t total = 138 + (size_t)w * h * 4;
     std::vector<unsigned char> d(total, 0);
@@ -603,4 +617,8 @@ extern "C" int wapt_write_bmp(const char* path, int32_t w, int32_t h, const floa
     if (!of) return wapt_fail(WAPT_E_IO, std::string("cannot write ") + path);
     of.write((const char*)d.data(), (std::streamsize)total);
     return of ? WAPT_OK : wapt_fail(WAPT_E_IO, std::string("write failed: ") + path);
+}
+
+extern "C" int wapt_write_bmp(const char* path, int32_t w, int32_t h, const float* px) {
+    return wapt_guarded([&] { return write_bmp(path, w, h, px); });
 }

@@ -44,7 +44,26 @@ struct TraceMem {
     uint32_t spill_stride;             // lanes of the largest launch
     int32_t stack_cap;                 // WAPT_LDS_STACK + spill entries per lane (>= depth of the tree)
     int32_t tri_quorum;                // lanes with pending triangles that trigger the triangle loop
+    uint32_t n_nodes, n_tris;          // record counts (read by the index-checking build only)
 };
+
+// -DWAPT_CHECK_INDICES: every index that the traversal and the shadow / probe kernels compute is compared with its
+// limit before it is used; a violation is printed and the index replaced by 0, so that the launch finishes and
+// the message is seen instead of a memory fault.  A debugging build: the product build compiles none of it.
+#ifdef WAPT_CHECK_INDICES
+#define WAPT_CHECK_IDX(i, n, what)                                                                         \
+    do {                                                                                                   \
+        if (!((unsigned long long)(i) < (unsigned long long)(n))) {                                        \
+            printf("wapt index check: %s = %llu, limit %llu (block %u thread %u)\n", what,                 \
+                   (unsigned long long)(i), (unsigned long long)(n), (unsigned)blockIdx.x, (unsigned)threadIdx.x); \
+            (i) = 0;                                                                                       \
+        }                                                                                                  \
+    } while (0)
+#else
+#define WAPT_CHECK_IDX(i, n, what) \
+    do {                           \
+    } while (0)
+#endif
 
 struct TraceCount {
     uint32_t nodes, tris, spills, overflow;
@@ -207,7 +226,8 @@ __device__ __forceinline__ void tri_phase_coop(const TraceMem& m, Trav& t, bool 
         const float tmin = __shfl(t.tmin, src);
         const float tmax = __uint_as_float((uint32_t)(cl->best[src] >> 32));
         if (valid) {
-            const uint32_t ti = tbase + k;
+            uint32_t ti = tbase + k;
+            WAPT_CHECK_IDX(ti, m.n_tris, "triangle (cooperative phase)");
             const float4* tp = m.tris + (uint32_t)(ti * 3u);
             float4 a = tp[0], b = tp[1], c = tp[2];
             if (COUNT) cnt.tris++;
@@ -268,6 +288,8 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
         // current group exhausted: pop, or finish
         if (t.sp == 0) return true;
         t.sp--;
+        WAPT_CHECK_IDX(t.sp, m.stack_cap, "stack pointer (pop)");
+        WAPT_CHECK_IDX(glane, m.spill_stride > 0u ? m.spill_stride : 0xffffffffu, "lane of the launch");
         t.G = (t.sp < WAPT_LDS_STACK) ? lds[t.sp * WAPT_BLOCK]
                                       : m.spill[(size_t)(t.sp - WAPT_LDS_STACK) * m.spill_stride + glane];
     }
@@ -277,6 +299,7 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
         uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
         t.G.y &= ~(1u << bit);
         if (t.G.y & 0xff000000u) {
+            WAPT_CHECK_IDX(t.sp, m.stack_cap + 1, "stack pointer (push)");
             if (t.sp < WAPT_LDS_STACK) {
                 lds[t.sp * WAPT_BLOCK] = t.G;
                 t.sp++;
@@ -291,6 +314,7 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
         uint32_t slot = (bit - 24u) ^ t.octinv;
         uint32_t rel = __popc(hits_imask & 0xffu & ((1u << slot) - 1u));
         uint32_t ni = t.G.x + rel;
+        WAPT_CHECK_IDX(ni, m.n_nodes, "node");
         const uint4* np = m.nodes + (uint32_t)(ni * 5u);  // (32-bit index arithmetic: a 64-bit multiply runs at quarter rate)
         uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
         if (COUNT) cnt.nodes++;
@@ -334,6 +358,7 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
             uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
             bits &= bits - 1u;
             uint32_t ti = t.T.x + k;
+            WAPT_CHECK_IDX(ti, m.n_tris, "triangle");
             const float4* tp = m.tris + (uint32_t)(ti * 3u);
             float4 a = tp[0], b = tp[1], c = tp[2];
             // (the flag word is only looked at for accepted hits: without this the compiler moves its load
@@ -482,7 +507,7 @@ struct WaveFeed {
         if (next >= end && !dry) {
             uint32_t k = 0;
             if (__lane_id() == 0) k = atomicAdd(counter, 1u);
-            k = (uint32_t)__shfl((int)k, 0);
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);  // (all lanes are here together: the first one is lane 0)
             unsigned long long b = ((unsigned long long)k * WAPT_FEED_SHARDS + shard) << gshift;
             if (b >= n) {
                 dry = true;

@@ -813,7 +813,11 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
     unsigned long long m = __ballot(pred);
     if (m == 0ull) return;
     uint32_t lane = lane_id();
-    if (pred) stage[__popcll(m & ((1ull << lane) - 1ull))] = make_float4(c.x, c.y, c.z, u2f(pixel));
+    if (pred) {
+        uint32_t at = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        WAPT_CHECK_IDX(at, 64u, "staging slot of a pixel add");
+        stage[at] = make_float4(c.x, c.y, c.z, u2f(pixel));
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -873,6 +877,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
     for (;;) {
         uint32_t idx = feed.take(!have_task);
         if (idx != 0xffffffffu) {
+            WAPT_CHECK_IDX(idx, n, "shadow task");
             float4 a = q.SA[idx], b = q.SB[idx];
             float4 w4s = q.SC[idx];
             cw = v3(w4s.x, w4s.y, w4s.z);
@@ -898,7 +903,9 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             // refined distance and the reference's thresholds.
             float rest = ABl - d, margin = 0.002f + 1e-4f * ABl;
             trav_begin(t, t.o, t.d, WAPT_TRACE_BIAS, rest + margin);
-            t.tblock = sc.fast_shadow ? rest - margin : -1.0f;  // (the step-by-step path searches for the closest hit)
+            // (never negative here: a negative value is how the search reports that it stopped at an opaque surface; with a
+            //  remaining way shorter than the margin the stop simply never fires)
+            t.tblock = sc.fast_shadow ? fmaxf(rest - margin, 0.0f) : -1.0f;  // (the step-by-step path searches for the closest hit)
             have_ray = true;
             rays++;
         }
@@ -945,9 +952,11 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                     // (the last step of the general path, cpp:764-775)
                     float seg = ABl;
                     if (it > 0) {
+                        WAPT_CHECK_IDX(task, q.capS, "shadow task (re-read of B)");
                         float4 b = q.SB[task];
                         seg = mag(v3(b.x, b.y, b.z) - t.o);
                     }
+                    WAPT_CHECK_IDX(cur, sc.n_objects + 1, "medium of a shadow walk");
                     V = V * attenuation(sc.mats[cur], seg);
                     lit = true;
                 } else {
@@ -974,6 +983,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                 if (d <= ABl + WAPT_TRACE_BIAS) {
                     int prim;
                     V3 N = normalized(tri_normal(sc.tm.tris, tri, &obj, &prim));
+                    WAPT_CHECK_IDX(obj, sc.n_objects, "object of a shadow walk's hit");
                     const DMaterial& m = sc.mats[obj];
                     P1 = hp;
                     seg = mag(P1 - P0);
@@ -991,6 +1001,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                     P1 = P0;
                     seg = ABl;
                     if (it > 0) {
+                        WAPT_CHECK_IDX(task, q.capS, "shadow task (re-read of B, general path)");
                         float4 b = q.SB[task];
                         seg = mag(v3(b.x, b.y, b.z) - P0);
                     }
@@ -1015,6 +1026,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
         uint32_t pixel = 0;
         if (lit) {
             pixel = cpixel;
+            WAPT_CHECK_IDX(pixel, (uint32_t)(sc.cam.resI * sc.cam.resJ), "pixel of a shadow task");
             contrib = cw * V;
             DBG(pixel, "shadow task=%u lit V=%g w=%g d=%.6f ABl=%.6f\n", task, V.x, cw.x, d, ABl);
         }
@@ -1095,6 +1107,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
     for (;;) {
         uint32_t idx = feed.take(!have_task);
         if (idx != 0xffffffffu) {
+            WAPT_CHECK_IDX(idx, n, "probe task");
             float4 a = q.PA[idx], b = q.PB[idx];
             const uint32_t info = f2u(b.w);
             task = idx;
@@ -1293,6 +1306,8 @@ struct wapt_scene {
     int n_lights = 0;
     wapt_camera camera;  // as described by the caller (the progressive interface re-derives lower resolutions from it)
     std::vector<hipEvent_t> ev_pool;
+    float* d_sum = nullptr;      // W*H*3 sums of wapt_render (kept between calls)
+    std::vector<struct wapt_progressive*> progressives;  // live progressive handles on this scene
 };
 
 namespace {
@@ -1384,6 +1399,8 @@ DCamera to_device(const wapt_camera& c) {
     return d;
 }
 
+const uint64_t WAPT_MAX_TRIS = 0xffffffffull / 3, WAPT_MAX_NODES = 0xffffffffull / 5;
+
 int validate_desc(const wapt_scene_desc* d) {
     if (!d) return wapt_fail(WAPT_E_INVALID, "null scene description");
     if (d->n_tris == 0 || !d->tri_verts || !d->tri_obj) return wapt_fail(WAPT_E_INVALID, "scene has no triangles");
@@ -1395,6 +1412,8 @@ int validate_desc(const wapt_scene_desc* d) {
     if (d->camera.resI <= 0 || d->camera.resJ <= 0) return wapt_fail(WAPT_E_INVALID, "bad resolution");
     if ((uint64_t)d->camera.resI * (uint64_t)d->camera.resJ >= (1ull << 30))
         return wapt_fail(WAPT_E_LIMIT, "image larger than 2^30 pixels");
+    // the traversal addresses triangle and node records with 32-bit arithmetic (3 and 5 sixteen-byte words each)
+    if (d->n_tris > WAPT_MAX_TRIS) return wapt_fail(WAPT_E_LIMIT, "more than (2^32-1)/3 triangles");
     for (uint64_t t = 0; t < d->n_tris; t++)
         if (d->tri_obj[t] < 0 || d->tri_obj[t] >= d->n_objects)
             return wapt_fail(WAPT_E_INVALID, "triangle refers to an object outside the material table");
@@ -1418,7 +1437,13 @@ extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wa
     return wapt_scene_create_with(desc, device, WAPT_BUILDER_AUTO, out);
 }
 
+static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_t builder, wapt_scene** out);
+
 extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_t builder, wapt_scene** out) {
+    return wapt_guarded([&] { return scene_create_with(desc, device, builder, out); });
+}
+
+static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_t builder, wapt_scene** out) {
     if (!out) return wapt_fail(WAPT_E_INVALID, "null output");
     *out = nullptr;
     int rc = validate_desc(desc);
@@ -1439,12 +1464,11 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     }
 
     HIPCHK(hipSetDevice(device));
-    auto s = new wapt_scene();
+    // (the holder frees whatever has been allocated so far on every way out, an exception included)
+    std::unique_ptr<wapt_scene, void (*)(wapt_scene*)> holder(new wapt_scene(), wapt_scene_destroy);
+    wapt_scene* const s = holder.get();
     s->device = device;
-    auto bail = [&](int code) {
-        wapt_scene_destroy(s);
-        return code;
-    };
+    auto bail = [&](int code) { return code; };
 #define HIPCHK_S(call)                                                                                       \
     do {                                                                                                     \
         hipError_t _e = (call);                                                                              \
@@ -1492,6 +1516,8 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
         HIPCHK_S(hipMemcpy(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice));
         HIPCHK_S(hipMemcpy(s->d_tris, bvh.tris.data(), bvh.tris.size() * sizeof(Bvh8Tri), hipMemcpyHostToDevice));
     }
+    if (s->n_nodes > WAPT_MAX_NODES || s->n_tris > WAPT_MAX_TRIS)
+        return bail(wapt_fail(WAPT_E_LIMIT, "BVH larger than the traversal's 32-bit record addressing allows"));
     s->builder = builder;
     s->build_seconds = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
 
@@ -1575,6 +1601,8 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     s->ks.tm.spill_stride = 0;
     s->ks.tm.stack_cap = WAPT_LDS_STACK;
     s->ks.tm.tri_quorum = (int32_t)env_u32("WAPT_TRI_QUORUM", 1);
+    s->ks.tm.n_nodes = (uint32_t)s->n_nodes;
+    s->ks.tm.n_tris = (uint32_t)s->n_tris;
     s->ks.mats = (const DMaterial*)s->d_mats;
     s->ks.lights = (const DLight*)s->d_lights;
     s->ks.n_lights = desc->n_lights;
@@ -1595,15 +1623,22 @@ extern "C" int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t devic
     s->ks.wr = desc->world_radius;
     memset(&s->kq, 0, sizeof(s->kq));
     HIPCHK_S(hipDeviceSynchronize());
-    *out = s;
+    *out = holder.release();
     return WAPT_OK;
 #undef HIPCHK_S
 }
+
+// Cuts a progressive handle loose from a scene that is going away: its device buffers are freed and every later
+// call on it reports an error instead of touching the freed scene (wapt_progressive_destroy still deletes it).
+static void progressive_orphan(wapt_progressive* p);
 
 extern "C" void wapt_scene_destroy(wapt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (wapt_progressive* p : s->progressives) progressive_orphan(p);
+    s->progressives.clear();
+    (void)hipFree(s->d_sum);
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(s->d_nodes);
     (void)hipFree(s->d_tris);
@@ -1826,7 +1861,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
 }  // namespace
 
 extern "C" int wapt_render_accumulate(wapt_scene* s, const wapt_render_params* prm, float* d_sum, wapt_stats* stats) {
-    return render_accumulate_view(s, prm, d_sum, stats, nullptr);
+    return wapt_guarded([&] { return render_accumulate_view(s, prm, d_sum, stats, nullptr); });
 }
 
 namespace {
@@ -2094,25 +2129,25 @@ __global__ void k_resolve(const float* sum, float* out, size_t n, float scale) {
     if (i < n) out[i] = sum[i] * scale;
 }
 
-extern "C" int wapt_render(wapt_scene* s, const wapt_render_params* prm, float* fb, wapt_stats* stats) {
+static int render_impl(wapt_scene* s, const wapt_render_params* prm, float* fb, wapt_stats* stats) {
     if (!s || !prm || !fb) return wapt_fail(WAPT_E_INVALID, "null argument");
     if (prm->sample_begin != 0 || prm->sample_count != prm->psamples)
         return wapt_fail(WAPT_E_INVALID, "wapt_render renders all samples: sample_begin=0, sample_count=psamples");
     HIPCHK(hipSetDevice(s->device));
-    size_t n = (size_t)s->ks.cam.resI * s->ks.cam.resJ * 3;
-    float* d_sum = nullptr;
-    HIPCHK(hipMalloc((void**)&d_sum, n * sizeof(float)));
-    hipError_t e = hipMemsetAsync(d_sum, 0, n * sizeof(float), s->stream);
-    int rc = e == hipSuccess ? wapt_render_accumulate(s, prm, d_sum, stats) : wapt_fail(WAPT_E_HIP, hipGetErrorString(e));
-    if (rc == WAPT_OK) {
-        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d_sum, d_sum, n,
-                           1.0f / (float)prm->psamples);
-        e = hipMemcpyAsync(fb, d_sum, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-        if (e != hipSuccess) rc = wapt_fail(WAPT_E_HIP, hipGetErrorString(e));
-    }
-    (void)hipFree(d_sum);
-    return rc;
+    const size_t n = (size_t)s->ks.cam.resI * s->ks.cam.resJ * 3;
+    if (!s->d_sum) HIPCHK(hipMalloc((void**)&s->d_sum, n * sizeof(float)));  // (the resolution of a scene is fixed)
+    HIPCHK(hipMemsetAsync(s->d_sum, 0, n * sizeof(float), s->stream));
+    int rc = render_accumulate_view(s, prm, s->d_sum, stats, nullptr);
+    if (rc != WAPT_OK) return rc;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->d_sum, s->d_sum, n,
+                       1.0f / (float)prm->psamples);
+    HIPCHK(hipMemcpyAsync(fb, s->d_sum, n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return WAPT_OK;
+}
+
+extern "C" int wapt_render(wapt_scene* s, const wapt_render_params* prm, float* fb, wapt_stats* stats) {
+    return wapt_guarded([&] { return render_impl(s, prm, fb, stats); });
 }
 
 // ---- progressive interface (udp_renderer::reset / setIterationCount / setRenderResolution / setRegion /
@@ -2137,7 +2172,8 @@ __global__ void k_replicate(float* fb, const float* avg, int dispW, int dispH, i
 }
 
 struct wapt_progressive {
-    wapt_scene* s = nullptr;
+    wapt_scene* s = nullptr;   // null once the scene has been destroyed
+    int device = 0;
     wapt_render_params prm;
     wapt_camera cam;           // display camera
     int dispW = 0, dispH = 0, renW = 0, renH = 0, rf = 1;
@@ -2147,12 +2183,36 @@ struct wapt_progressive {
     std::atomic<int> abort_flag{0};
 };
 
-extern "C" int wapt_progressive_create(wapt_scene* s, const wapt_render_params* prm, wapt_progressive** out) {
+static void progressive_free_buffers(wapt_progressive* p) {
+    (void)hipSetDevice(p->device);
+    (void)hipFree(p->d_avg);
+    (void)hipFree(p->d_sum);
+    (void)hipFree(p->d_fb);
+    p->d_avg = p->d_sum = p->d_fb = nullptr;
+}
+
+static void progressive_orphan(wapt_progressive* p) {
+    progressive_free_buffers(p);
+    p->s = nullptr;
+}
+
+#define PROG_ALIVE(p)                                                                              \
+    do {                                                                                           \
+        if (!(p)) return wapt_fail(WAPT_E_INVALID, "null argument");                               \
+        if (!(p)->s) return wapt_fail(WAPT_E_INVALID, "the scene of this progressive handle has been destroyed"); \
+    } while (0)
+
+static int progressive_create(wapt_scene* s, const wapt_render_params* prm, wapt_progressive** out) {
     if (!s || !prm || !out) return wapt_fail(WAPT_E_INVALID, "null argument");
+    *out = nullptr;
     if (prm->psamples <= 0) return wapt_fail(WAPT_E_INVALID, "psamples must be positive");
     HIPCHK(hipSetDevice(s->device));
-    std::unique_ptr<wapt_progressive> p(new wapt_progressive());
+    std::unique_ptr<wapt_progressive, void (*)(wapt_progressive*)> p(new wapt_progressive(), [](wapt_progressive* q) {
+        progressive_free_buffers(q);
+        delete q;
+    });
     p->s = s;
+    p->device = s->device;
     p->prm = *prm;
     p->cam = s->camera;
     p->dispW = p->renW = s->camera.resI;
@@ -2165,21 +2225,29 @@ extern "C" int wapt_progressive_create(wapt_scene* s, const wapt_render_params* 
     HIPCHK(hipMalloc((void**)&p->d_fb, bytes));
     HIPCHK(hipMemset(p->d_avg, 0, bytes));
     HIPCHK(hipMemset(p->d_fb, 0, bytes));
+    s->progressives.push_back(p.get());
     *out = p.release();
     return WAPT_OK;
 }
 
+extern "C" int wapt_progressive_create(wapt_scene* s, const wapt_render_params* prm, wapt_progressive** out) {
+    return wapt_guarded([&] { return progressive_create(s, prm, out); });
+}
+
 extern "C" void wapt_progressive_destroy(wapt_progressive* p) {
     if (!p) return;
-    (void)hipSetDevice(p->s->device);
-    (void)hipFree(p->d_avg);
-    (void)hipFree(p->d_sum);
-    (void)hipFree(p->d_fb);
+    if (p->s) {
+        auto& v = p->s->progressives;
+        v.erase(std::remove(v.begin(), v.end(), p), v.end());
+        (void)hipSetDevice(p->device);
+        if (p->s->stream) (void)hipStreamSynchronize(p->s->stream);
+    }
+    progressive_free_buffers(p);
     delete p;
 }
 
 extern "C" int wapt_progressive_reset(wapt_progressive* p) {
-    if (!p) return wapt_fail(WAPT_E_INVALID, "null argument");
+    PROG_ALIVE(p);
     HIPCHK(hipSetDevice(p->s->device));
     p->it = 0;
     HIPCHK(hipMemsetAsync(p->d_avg, 0, (size_t)p->dispW * p->dispH * 3 * sizeof(float), p->s->stream));
@@ -2193,7 +2261,8 @@ extern "C" int wapt_progressive_set_iteration(wapt_progressive* p, int32_t it) {
 }
 
 extern "C" int wapt_progressive_set_resolution(wapt_progressive* p, int32_t downres_pow2) {
-    if (!p || downres_pow2 < 0 || downres_pow2 > 12) return wapt_fail(WAPT_E_INVALID, "bad resolution exponent");
+    PROG_ALIVE(p);
+    if (downres_pow2 < 0 || downres_pow2 > 12) return wapt_fail(WAPT_E_INVALID, "bad resolution exponent");
     // lowerResolution (cpp:924-934)
     int w_new = (int)((float)p->dispW / powf(2.0f, (float)downres_pow2));
     int h_new = (int)((float)p->dispH / powf(2.0f, (float)downres_pow2));
@@ -2210,7 +2279,7 @@ extern "C" int wapt_progressive_set_resolution(wapt_progressive* p, int32_t down
 }
 
 extern "C" int wapt_progressive_set_region(wapt_progressive* p, int32_t l, int32_t r, int32_t b, int32_t t) {
-    if (!p) return wapt_fail(WAPT_E_INVALID, "null argument");
+    PROG_ALIVE(p);
     if (l < 0 || b < 0 || r > p->renW || t > p->renH || l >= r || b >= t)
         return wapt_fail(WAPT_E_INVALID, "region outside the render resolution");
     p->l = l;
@@ -2220,6 +2289,8 @@ extern "C" int wapt_progressive_set_region(wapt_progressive* p, int32_t l, int32
     return WAPT_OK;
 }
 
+static int progressive_render(wapt_progressive* p, float* fb, wapt_stats* stats);
+
 extern "C" int wapt_progressive_abort(wapt_progressive* p) {
     if (!p) return wapt_fail(WAPT_E_INVALID, "null argument");
     p->abort_flag.store(1);
@@ -2227,7 +2298,12 @@ extern "C" int wapt_progressive_abort(wapt_progressive* p) {
 }
 
 extern "C" int wapt_progressive_render(wapt_progressive* p, float* fb, wapt_stats* stats) {
-    if (!p || !fb) return wapt_fail(WAPT_E_INVALID, "null argument");
+    return wapt_guarded([&] { return progressive_render(p, fb, stats); });
+}
+
+static int progressive_render(wapt_progressive* p, float* fb, wapt_stats* stats) {
+    PROG_ALIVE(p);
+    if (!fb) return wapt_fail(WAPT_E_INVALID, "null argument");
     wapt_scene* s = p->s;
     HIPCHK(hipSetDevice(s->device));
     p->abort_flag.store(0);
@@ -2283,8 +2359,8 @@ extern "C" int wapt_generate_tiles(int32_t renW, int32_t renH, int32_t subdiv_le
     return WAPT_OK;
 }
 
-extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wapt_hit* d_hits,
-                                     wapt_trace_counters* counters, float* ms) {
+static int intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wapt_hit* d_hits,
+                            wapt_trace_counters* counters, float* ms) {
     if (!s || (n && (!d_rays || !d_hits))) return wapt_fail(WAPT_E_INVALID, "null argument");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipMemsetAsync(s->d_rays, 0, 16 * sizeof(unsigned long long), s->stream));
@@ -2332,7 +2408,18 @@ extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint
     return WAPT_OK;
 }
 
+extern "C" int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wapt_hit* d_hits,
+                                     wapt_trace_counters* counters, float* ms) {
+    return wapt_guarded([&] { return intersect_device(s, d_rays, n, d_hits, counters, ms); });
+}
+
+static int intersect_host(wapt_scene* s, const wapt_ray* rays, uint32_t n, wapt_hit* hits);
+
 extern "C" int wapt_intersect(wapt_scene* s, const wapt_ray* rays, uint32_t n, wapt_hit* hits) {
+    return wapt_guarded([&] { return intersect_host(s, rays, n, hits); });
+}
+
+static int intersect_host(wapt_scene* s, const wapt_ray* rays, uint32_t n, wapt_hit* hits) {
     if (!s || (n && (!rays || !hits))) return wapt_fail(WAPT_E_INVALID, "null argument");
     if (n == 0) return WAPT_OK;
     HIPCHK(hipSetDevice(s->device));
@@ -2347,7 +2434,7 @@ extern "C" int wapt_intersect(wapt_scene* s, const wapt_ray* rays, uint32_t n, w
     int rc = WAPT_OK;
     e = hipMemcpy(d_r, rays, (size_t)n * sizeof(wapt_ray), hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = wapt_fail(WAPT_E_HIP, hipGetErrorString(e));
-    if (rc == WAPT_OK) rc = wapt_intersect_device(s, d_r, n, d_h, nullptr, nullptr);
+    if (rc == WAPT_OK) rc = intersect_device(s, d_r, n, d_h, nullptr, nullptr);
     if (rc == WAPT_OK) {
         e = hipMemcpy(hits, d_h, (size_t)n * sizeof(wapt_hit), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = wapt_fail(WAPT_E_HIP, hipGetErrorString(e));

@@ -1,5 +1,7 @@
 // Internals shared by the translation units of libwapt.so (not installed).
 #pragma once
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -7,6 +9,33 @@
 
 // Records the message returned by wapt_last_error() and returns `code`.
 int wapt_fail(int code, const std::string& msg);
+
+// Runs the body of an extern "C" entry point: no C++ exception leaves the library.  Running out of host memory
+// becomes WAPT_E_LIMIT, anything else WAPT_E_INVALID with the exception's text.
+template <class F>
+int wapt_guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try {
+            return wapt_fail(WAPT_E_LIMIT, "out of memory");  // (short enough to need no allocation itself)
+        } catch (...) {
+            return WAPT_E_LIMIT;
+        }
+    } catch (const std::exception& e) {
+        try {
+            return wapt_fail(WAPT_E_INVALID, std::string("internal error: ") + e.what());
+        } catch (...) {
+            return WAPT_E_INVALID;
+        }
+    } catch (...) {
+        try {
+            return wapt_fail(WAPT_E_INVALID, "internal error");
+        } catch (...) {
+            return WAPT_E_INVALID;
+        }
+    }
+}
 
 // Parsed .waff file + loaded meshes, flattened the way wa_content::init
 // (src/content.cpp:13-40) numbers objects.

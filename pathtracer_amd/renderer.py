@@ -43,6 +43,8 @@ class wa_content:
         return hits
 
     def close(self):
+        """Frees the scene.  Progressive handles of renderers on this content stay valid to close, nothing else:
+        the library cuts them loose from the scene before it goes."""
         if self._h:
             capi.wapt_scene_destroy(self._h)
             self._h = C.c_void_p()
@@ -87,6 +89,9 @@ class udp_renderer:
             raise ValueError("frame buffer must be contiguous float32 with W*H*3 elements")
         self.params.profile = int(profile)
         if self._prog:
+            if profile:
+                # (the progressive handle copied the parameters when it was created)
+                raise ValueError("profile is not available through the progressive interface")
             capi.check(capi.wapt_progressive_render(self._prog, buffer.ctypes.data, C.byref(self.stats)))
             return buffer
         self.params.sample_begin, self.params.sample_count = 0, self.params.psamples

@@ -120,6 +120,18 @@ static int run_fuzz(const std::string& dir) {
         spit(dir + "/ball.fast", t);
         try_waff(waff);
     }
+    // headers that promise far more than the file holds (a count of 0x7fffffff would size a 32 GiB vector)
+    for (int which = 0; which < 3; which++) {
+        std::string t = fast;
+        const int32_t huge = 0x7fffffff;
+        if (which != 1) memcpy(&t[0], &huge, 4);
+        if (which != 0) memcpy(&t[4], &huge, 4);
+        spit(dir + "/ball.fast", t);
+        wapt_waff* w = nullptr;
+        CHECK(wapt_waff_load((dir + "/test.waff").c_str(), &w) == WAPT_E_IO);
+        CHECK(w == nullptr);
+        bad++;
+    }
     spit(dir + "/ball.fast", fast);
     for (size_t cut = 0; cut <= obj.size(); cut += 11) {
         spit(dir + "/f.obj", obj.substr(0, cut));
