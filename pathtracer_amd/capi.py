@@ -62,6 +62,7 @@ wapt_render_accumulate = _proto("wapt_render_accumulate", C.c_int, vp, P(abi.Ren
 wapt_intersect = _proto("wapt_intersect", C.c_int, vp, vp, C.c_uint32, vp)
 wapt_intersect_device = _proto("wapt_intersect_device", C.c_int, vp, vp, C.c_uint32, vp, P(abi.TraceCounters),
                                P(C.c_float))
+wapt_intersect_device_static = _proto("wapt_intersect_device_static", C.c_int, vp, vp, C.c_uint32, vp)
 wapt_progressive_create = _proto("wapt_progressive_create", C.c_int, vp, P(abi.RenderParams), P(vp))
 wapt_progressive_destroy = _proto("wapt_progressive_destroy", None, vp)
 wapt_progressive_reset = _proto("wapt_progressive_reset", C.c_int, vp)
@@ -76,7 +77,7 @@ EXPORTS = [
     "wapt_last_error", "wapt_version", "wapt_waff_load", "wapt_waff_desc", "wapt_waff_settings", "wapt_waff_free",
     "wapt_convert_obj_to_fast", "wapt_tonemap", "wapt_write_bmp", "wapt_scene_create", "wapt_scene_create_with",
     "wapt_scene_destroy",
-    "wapt_scene_bvh_info", "wapt_render", "wapt_render_accumulate", "wapt_intersect", "wapt_intersect_device",
+    "wapt_scene_bvh_info", "wapt_render", "wapt_render_accumulate", "wapt_intersect", "wapt_intersect_device", "wapt_intersect_device_static",
     "wapt_progressive_create", "wapt_progressive_destroy", "wapt_progressive_reset", "wapt_progressive_set_iteration",
     "wapt_progressive_set_resolution", "wapt_progressive_set_region", "wapt_progressive_render",
     "wapt_progressive_abort", "wapt_generate_tiles",

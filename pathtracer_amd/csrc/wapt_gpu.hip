@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cfloat>
 #include <memory>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -1276,6 +1277,38 @@ __global__ __launch_bounds__(WAPT_BLOCK) void k_intersect(TraceMem tm, const flo
             return wapt_fail(WAPT_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e));              \
     } while (0)
 
+// ---- device memory that exists without any allocation (wapt_intersect_device_static) ------------------------
+// One array per GPU, part of the loaded code object, held until the process ends.  Layout:
+//   [0, 8 KiB)        32 work-feed counters of the traversal kernel, one per 256-byte line
+//   [8 KiB, 16 KiB)   8 x 64-bit result counters (word 3: traversal-stack pushes dropped)
+//   [16 KiB, 32 MiB)  spill area of the traversal stacks: (tree depth - WAPT_LDS_STACK) entries per lane of the launch
+// In host code the array's name is only a handle for hipGetSymbolAddress: each GPU has its own copy at its own
+// address, looked up once per device (static_scratch_of) and used through that pointer everywhere else.
+#define WAPT_STATIC_SCRATCH_BYTES (32u << 20)
+#define WAPT_STATIC_HEADER_BYTES (16u << 10)
+#define WAPT_STATIC_MAX_RAYS (1u << 30)
+static __device__ __align__(256) unsigned char scratch[WAPT_STATIC_SCRATCH_BYTES];
+
+namespace {
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[64] = {};  // per device
+
+// Address of device `device`'s copy of the array; the device must be current.
+int static_scratch_of(int device, unsigned char** out) {
+    if (device < 0 || device >= 64) return wapt_fail(WAPT_E_LIMIT, "device index beyond 63");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return wapt_fail(WAPT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return WAPT_OK;
+}
+}  // namespace
+
 struct wapt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1307,6 +1340,7 @@ struct wapt_scene {
     wapt_camera camera;  // as described by the caller (the progressive interface re-derives lower resolutions from it)
     std::vector<hipEvent_t> ev_pool;
     float* d_sum = nullptr;      // W*H*3 sums of wapt_render (kept between calls)
+    unsigned char* static_scratch = nullptr;  // this GPU's copy of the file-scope scratch array (wapt_intersect_device_static)
     std::vector<struct wapt_progressive*> progressives;  // live progressive handles on this scene
 };
 
@@ -1476,6 +1510,9 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     } while (0)
 
     HIPCHK_S(hipStreamCreate(&s->stream));
+    // this GPU's copy of the static scratch array, looked up once per device with the device current (a failure is
+    // reported by the one entry point that needs the array, wapt_intersect_device_static)
+    if (static_scratch_of(device, &s->static_scratch) != WAPT_OK) s->static_scratch = nullptr;
     auto tb0 = std::chrono::steady_clock::now();
     float blo[3], bhi[3];
     if (builder == WAPT_BUILDER_DEVICE_LBVH) {
@@ -2442,4 +2479,41 @@ static int intersect_host(wapt_scene* s, const wapt_ray* rays, uint32_t n, wapt_
     (void)hipFree(d_r);
     (void)hipFree(d_h);
     return rc;
+}
+
+// The closest-hit batch of wapt_intersect_device for callers that cannot allocate: everything the launch needs
+// beyond the caller's rays and hits lives in this GPU's copy of `scratch`.  No hipMalloc / hipFree here or below.
+static int intersect_device_static(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wapt_hit* d_hits) {
+    if (!s || (n && (!d_rays || !d_hits))) return wapt_fail(WAPT_E_INVALID, "null argument");
+    if (n > WAPT_STATIC_MAX_RAYS)
+        return wapt_fail(WAPT_E_LIMIT, "wapt_intersect_device_static takes at most 2^30 rays per call (got " + std::to_string(n) + ")");
+    if (n == 0) return WAPT_OK;
+    HIPCHK(hipSetDevice(s->device));
+    unsigned char* const base = s->static_scratch;
+    if (!base) return wapt_fail(WAPT_E_HIP, "the static scratch array of this device was not found at scene creation");
+    // the stack spill area is cut to the lanes that fit: a deeper tree runs with fewer blocks
+    int depth_slots = std::max(1, (int)s->bvh_depth + 1 - WAPT_LDS_STACK);
+    depth_slots = std::min(depth_slots, WAPT_STACK_CAP - WAPT_LDS_STACK);
+    const size_t spill_bytes = WAPT_STATIC_SCRATCH_BYTES - WAPT_STATIC_HEADER_BYTES;
+    const uint32_t blocks = (uint32_t)std::min<size_t>(s->grid, spill_bytes / ((size_t)depth_slots * sizeof(uint2) * WAPT_BLOCK));
+    if (blocks == 0) return wapt_fail(WAPT_E_LIMIT, "BVH too deep for the static scratch array");
+    TraceMem tm = s->ks.tm;
+    tm.spill = (uint2*)(base + WAPT_STATIC_HEADER_BYTES);
+    tm.spill_stride = blocks * WAPT_BLOCK;
+    tm.stack_cap = WAPT_LDS_STACK + depth_slots;
+    // the array keeps what the last call left: feed counters and result counters start at zero
+    HIPCHK(hipMemsetAsync(base, 0, WAPT_STATIC_HEADER_BYTES, s->stream));
+    unsigned long long* const counters = (unsigned long long*)(base + (8u << 10));
+    hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(WAPT_BLOCK), 0, s->stream, tm, (const float4*)d_rays, n, (float*)d_hits,
+                       counters, (uint32_t*)base);
+    unsigned long long* const h = s->h_u64;  // pinned, allocated with the scene
+    HIPCHK(hipMemcpyAsync(h, counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    if (h[3]) return wapt_fail(WAPT_E_LIMIT, "traversal stack overflow");
+    return WAPT_OK;
+}
+
+extern "C" int wapt_intersect_device_static(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wapt_hit* d_hits) {
+    return wapt_guarded([&] { return intersect_device_static(s, d_rays, n, d_hits); });
 }
