@@ -79,4 +79,20 @@ struct KParams {
     int32_t write_hits;         // the scene has media: keep refined hits and the list of marched segments for k_volume
     int32_t pixel_major;        // task order: all samples of a pixel next to each other (else sample by sample;
                                 // experiment: without pre-reduction the pixel sums then contend, see WAPT_PIXEL_MAJOR)
+    // camera tasks made inside the depth-0 kernels: slot x of the step's chunk is sample cam_s0 + x / slots_per_sample,
+    // image slot x % slots_per_sample; the two divisions by launch constants as multiply-and-shift (udiv_magic)
+    uint32_t cam_s0;
+    uint32_t div_slots_m, div_slots_k, div_tiles_m, div_tiles_k;
 };
+
+// x / d for x < 2^31 as (x * m) >> k, with m = ceil(2^k / d), k = 31 + ceil(log2 d): the error term x * (m d - 2^k)
+// stays below 2^k for such x, so the quotient is exact.
+inline void udiv_magic(uint32_t d, uint32_t* m, uint32_t* k) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    *k = 31u + l;
+    *m = (uint32_t)(((1ull << *k) + d - 1u) / d);
+}
+__device__ __forceinline__ uint32_t udiv_by(uint32_t x, uint32_t m, uint32_t k) {
+    return (uint32_t)(((unsigned long long)x * (unsigned long long)m) >> k);
+}

@@ -309,37 +309,69 @@ __global__ void k_reset_sp(uint32_t* cnt) {
     cnt[CNT_FEED + (32 + t) * WAPT_FEED_STRIDE] = 0u;  // 64 threads: feed counters of k_shadow and k_probe
 }
 
-// renderTile's sample loop + generateRayForPixel (cpp:122-132, fundamentals.cpp:306-327)
+// One iteration of renderTile's sample loop + generateRayForPixel (cpp:122-132, fundamentals.cpp:306-327): the camera
+// task number `path` of a call - its pixel, the key of its sample and its ray.  A pure function of (path, parameters):
+// the kernels of depth 0 can call it instead of reading the task from the queue.  False for a slot outside the image
+// or the rendered region.
+__device__ __forceinline__ bool camera_task(const KScene& sc, const KParams& p, unsigned long long path, V3* o, V3* d,
+                                            uint32_t* pixel_out, uint32_t* key_out) {
+    uint32_t s_local, r;
+    if (p.pixel_major) {
+        r = (uint32_t)(path / p.sample_count);
+        s_local = (uint32_t)(path % p.sample_count);
+    } else {
+        s_local = (uint32_t)(path / p.slots_per_sample);
+        r = (uint32_t)(path % p.slots_per_sample);
+    }
+    uint32_t tile = r >> 6, within = r & 63u;
+    int px = (int)((tile % p.tilesX) * 8u + (within & 7u));
+    int py = (int)((tile / p.tilesX) * 8u + (within >> 3));
+    const bool valid = px < sc.cam.resI && py < sc.cam.resJ && px >= p.rl && px < p.rr && py >= p.rb && py < p.rt;
+    uint32_t pixel = (uint32_t)(py * sc.cam.resI + px);
+    uint32_t key = wapt_key_root(p.seed, (uint32_t)p.sample_begin + s_local);
+    uint32_t stream = wapt_stream(key, pixel);
+    camera_ray(sc.cam, px, py, wapt_rand(stream, WAPT_DIM_CAM0), wapt_rand(stream, WAPT_DIM_CAM1), o, d);
+    *pixel_out = pixel;
+    *key_out = key;
+    return valid;
+}
+
+#define WAPT_CAMERA_INFO make_info(0, true, RAY_CAMERA, -1)
+
+// The same for slot x (< 2^31) of a chunk of camera tasks that starts on a whole sample: what the depth-0 kernels call
+// instead of reading the task.  No division instructions (see KParams::div_*); every slot is a pixel sample here
+// (whole image, dimensions multiples of 8).
+__device__ __forceinline__ void camera_task_at(const KScene& sc, const KParams& p, uint32_t x, V3* o, V3* d, uint32_t* pixel_out,
+                                               uint32_t* key_out) {
+    const uint32_t qs = udiv_by(x, p.div_slots_m, p.div_slots_k);
+    const uint32_t r = x - qs * p.slots_per_sample;
+    const uint32_t tile = r >> 6, within = r & 63u;
+    const uint32_t ty = udiv_by(tile, p.div_tiles_m, p.div_tiles_k);
+    const uint32_t tx = tile - ty * p.tilesX;
+    const int px = (int)(tx * 8u + (within & 7u));
+    const int py = (int)(ty * 8u + (within >> 3));
+    const uint32_t pixel = (uint32_t)(py * sc.cam.resI + px);
+    const uint32_t key = wapt_key_root(p.seed, (uint32_t)p.sample_begin + p.cam_s0 + qs);
+    const uint32_t stream = wapt_stream(key, pixel);
+    camera_ray(sc.cam, px, py, wapt_rand(stream, WAPT_DIM_CAM0), wapt_rand(stream, WAPT_DIM_CAM1), o, d);
+    *pixel_out = pixel;
+    *key_out = key;
+}
+
 __global__ __launch_bounds__(WAPT_SBLOCK) void k_raygen(KScene sc, KQueues q, KParams p, unsigned long long p0, uint32_t n) {
     GRID_LOOP(i, n) {
-        bool valid = i < n;
-        unsigned long long path = p0 + i;
-        uint32_t s_local, r;
-        if (p.pixel_major) {
-            r = (uint32_t)(path / p.sample_count);
-            s_local = (uint32_t)(path % p.sample_count);
-        } else {
-            s_local = (uint32_t)(path / p.slots_per_sample);
-            r = (uint32_t)(path % p.slots_per_sample);
-        }
-        uint32_t tile = r >> 6, within = r & 63u;
-        int px = (int)((tile % p.tilesX) * 8u + (within & 7u));
-        int py = (int)((tile / p.tilesX) * 8u + (within >> 3));
-        valid = valid && px < sc.cam.resI && py < sc.cam.resJ && px >= p.rl && px < p.rr && py >= p.rb && py < p.rt;
-        uint32_t pixel = (uint32_t)(py * sc.cam.resI + px);
-        uint32_t key = wapt_key_root(p.seed, (uint32_t)p.sample_begin + s_local);
-        uint32_t stream = wapt_stream(key, pixel);
         V3 o, d;
-        camera_ray(sc.cam, px, py, wapt_rand(stream, WAPT_DIM_CAM0), wapt_rand(stream, WAPT_DIM_CAM1), &o, &d);
+        uint32_t pixel, key;
+        const bool valid = camera_task(sc, p, p0 + i, &o, &d, &pixel, &key) && i < n;
         if (p.dense_raygen) {
             // every slot of the batch is a pixel sample: the task goes to slot i, no compaction needed
             if (i < n) {
                 q.RA[i] = make_float4(o.x, o.y, o.z, u2f(pixel));
-                q.RB[i] = make_float4(d.x, d.y, d.z, u2f(make_info(0, true, RAY_CAMERA, -1)));
+                q.RB[i] = make_float4(d.x, d.y, d.z, u2f(WAPT_CAMERA_INFO));
                 q.RC[i] = make_float4(1.f, 1.f, 1.f, u2f(key));
             }
         } else {
-            push_radiance(q, 0, valid, o, d, v3(1.f, 1.f, 1.f), pixel, make_info(0, true, RAY_CAMERA, -1), key);
+            push_radiance(q, 0, valid, o, d, v3(1.f, 1.f, 1.f), pixel, WAPT_CAMERA_INFO, key);
         }
     }
 }
@@ -348,8 +380,11 @@ __global__ __launch_bounds__(WAPT_SBLOCK) void k_raygen(KScene sc, KQueues q, KP
 // on demand (WaveFeed) and stream them through their lanes: a lane whose ray has ended takes the next one.
 // COUNT adds node-visit and triangle-test tallies (rays[1], rays[2]) for the bytes-per-ray figure of
 // the roofline.
-template <bool COUNT>
-__global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene sc, KQueues q, int depth, uint32_t start, uint32_t n) {
+// CAM: the step's tasks are camera tasks and are not in the queue: their rays are made here (camera_task_at, slot
+// start + i of the chunk) instead of read - no ray generation pass, no 48-byte task written and read back twice.
+template <bool COUNT, bool CAM = false>
+__global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene sc, KQueues q, int depth, uint32_t start, uint32_t n,
+                                                                        KParams p) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     __shared__ CoopLds s_coop[WAPT_BLOCK / 64];
     CoopLds* coop = &s_coop[threadIdx.x >> 6];
@@ -363,8 +398,15 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene s
     for (;;) {
         uint32_t idx = feed.take(!have);
         if (idx != 0xffffffffu) {
-            float4 a = q.RA[base + idx], b = q.RB[base + idx];
-            trav_begin(t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, WAPT_TFAR);
+            if (CAM) {
+                V3 o, d;
+                uint32_t pixel, key;
+                camera_task_at(sc, p, start + idx, &o, &d, &pixel, &key);
+                trav_begin(t, o, d, WAPT_TRACE_BIAS, WAPT_TFAR);
+            } else {
+                float4 a = q.RA[base + idx], b = q.RB[base + idx];
+                trav_begin(t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, WAPT_TFAR);
+            }
             cur = idx;
             have = true;
         }
@@ -408,7 +450,8 @@ __device__ __forceinline__ bool segment_marched(const KScene& sc, const HitCtx& 
 // may run different branches) so that nothing is read twice.
 // ONE: one hemisphere and one light sample per event (the reference's defaults): the sample loops are gone.
 // MEDIA: the scene has a participating medium (hit records are kept and marched segments listed for the march kernel).
-template <bool ONE, bool MEDIA>
+// CAM: camera tasks made on the spot, as in k_trace (depth 0 of a scene without media, whole image).
+template <bool ONE, bool MEDIA, bool CAM = false>
 __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
     const int lsamples = ONE ? 1 : p.lsamples, hsamples = ONE ? 1 : p.hsamples;
     enum { NONE, LAMBERT, MIRROR, DIELECTRIC };
@@ -423,7 +466,14 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
         V3 cdir = v3(0, 0, 1), cb = v3(0, 0, 0);
         uint32_t cinfo = 0, ckey = 0;
         if (valid) {
-            load_task(q, depth, start, i, c);
+            if (CAM) {
+                camera_task_at(sc, p, start + i, &c.o, &c.dir, &c.pixel, &c.key);
+                c.beta = v3(1.f, 1.f, 1.f);
+                c.info = WAPT_CAMERA_INFO;
+                c.stream = wapt_stream(c.key, c.pixel);
+            } else {
+                load_task(q, depth, start, i, c);
+            }
             uint2 h = q.hits[i];
             if (h.y != 0xffffffffu) {
                 // the closest-hit kernel leaves the fp32 distance of its search; the fp64 re-evaluation runs
@@ -1966,6 +2016,14 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         if (chunk_for(d) == 0)
             return wapt_fail(WAPT_E_LIMIT, "queue capacity too small for the fan-out of this scene and these settings");
 
+    // Camera tasks of a scene without media (whole image, dimensions multiples of 8) are never stored: the kernels of
+    // depth 0 make them from their slot number.  A chunk of camera tasks then holds whole samples
+    // (WAPT_FUSE_CAMERA=0 keeps the ray generation pass, for comparison).
+    const char* fuse_env = getenv("WAPT_FUSE_CAMERA");
+    const bool fuse_camera = kp.dense_raygen && !s->has_scatter && !kp.pixel_major && !(fuse_env && fuse_env[0] == '0') &&
+                             s->capR >= kp.slots_per_sample && s->capR < (1u << 31);
+    udiv_magic(kp.slots_per_sample, &kp.div_slots_m, &kp.div_slots_k);
+    udiv_magic(kp.tilesX, &kp.div_tiles_m, &kp.div_tiles_k);
     Timer tm{s, (prm->profile & 1) != 0, {}, 0};
     std::vector<uint32_t> have((size_t)td + 2, 0u);
     const unsigned long long total = (unsigned long long)kp.slots_per_sample * (unsigned long long)prm->sample_count;
@@ -1987,8 +2045,14 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
             if (view && view->abort && view->abort->load()) aborted = true;  // in-flight paths are finished, no new ones start
             if (issued >= total || aborted) break;
             uint32_t n = (uint32_t)std::min<unsigned long long>(s->capR, total - issued);
-            hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_R0, kp.dense_raygen ? n : 0u);
-            tm.run(FAM_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, sgrid, sblock, 0, st, ks, q, kp, issued, n); });
+            if (fuse_camera) {
+                n = (uint32_t)std::min<unsigned long long>((unsigned long long)(s->capR / kp.slots_per_sample) * kp.slots_per_sample, total - issued);
+                kp.cam_s0 = (uint32_t)(issued / kp.slots_per_sample);  // (chunks start on whole samples)
+            }
+            if (!fuse_camera) {
+                hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_R0, kp.dense_raygen ? n : 0u);
+                tm.run(FAM_RAYGEN, [&] { hipLaunchKernelGGL(k_raygen, sgrid, sblock, 0, st, ks, q, kp, issued, n); });
+            }
             issued += n;
             if (kp.dense_raygen) {
                 have[0] = n;
@@ -2004,9 +2068,12 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         have[d] = start;
         for (;;) {
             hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, d < td ? CNT_R(d + 1) : -1, 0u);
+            const bool cam = fuse_camera && d == 0;
             tm.run(FAM_TRACE, [&] {
-                if (prm->profile & 2) hipLaunchKernelGGL(k_trace<true>, grid, block, 0, st, ks, q, d, start, n);
-                else hipLaunchKernelGGL(k_trace<false>, grid, block, 0, st, ks, q, d, start, n);
+                if (cam && (prm->profile & 2)) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, st, ks, q, d, start, n, kp);
+                else if (cam) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, st, ks, q, d, start, n, kp);
+                else if (prm->profile & 2) hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, st, ks, q, d, start, n, kp);
+                else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, st, ks, q, d, start, n, kp);
             });
             if (!s->has_inside) break;
             // Scenes with a scattering object: chunk_for() bounds a segment inside an object by the object's box,
@@ -2034,7 +2101,10 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         n_trace_launches++;
         tm.run(FAM_SHADE, [&] {
             const bool one = prm->lsamples == 1 && prm->hsamples == 1;
-            if (one && !kp.write_hits) hipLaunchKernelGGL((k_surface<true, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+            const bool cam = fuse_camera && d == 0;
+            if (cam && one) hipLaunchKernelGGL((k_surface<true, false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+            else if (cam) hipLaunchKernelGGL((k_surface<false, false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+            else if (one && !kp.write_hits) hipLaunchKernelGGL((k_surface<true, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
             else if (one) hipLaunchKernelGGL((k_surface<true, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
             else if (!kp.write_hits) hipLaunchKernelGGL((k_surface<false, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
             else hipLaunchKernelGGL((k_surface<false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
