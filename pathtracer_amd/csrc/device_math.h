@@ -96,6 +96,9 @@ struct DLight {
     // the light object's triangles in the BVH (filled on the device after the tree is built): an area light's quad
     // is two, a sphere light has none (src/content.cpp:42-50 gives only area lights a geometry)
     int32_t ntri, tri0, tri1;
+    // area lights: no other object's surface lies in front of the quad closer than a shadow search can resolve
+    // (set at scene creation, see light_front_is_clear): a walk that ends on the quad may stop searching short of it
+    int32_t front_clear;
 };
 
 struct DCamera {

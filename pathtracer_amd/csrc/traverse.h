@@ -179,6 +179,10 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
 #ifndef WAPT_COOP_PER_LANE
 #define WAPT_COOP_PER_LANE 4
 #endif
+// 1: the one-search shadow kernel (scenes of opaque objects) uses the cooperative phase in its any-hit form
+#ifndef WAPT_SHADOW_COOP
+#define WAPT_SHADOW_COOP 0
+#endif
 struct CoopLds {
     unsigned long long best[64];
     uint16_t items[64 * WAPT_COOP_PER_LANE];
@@ -191,7 +195,10 @@ struct CoopLds {
 // round.)  A lane contributes at most WAPT_COOP_PER_LANE triangles per step and keeps the rest pending.
 // (Closest-hit searches only.  Shadow walks keep the sequential loop: they stop at the first opaque hit, keep 41 % of
 // that loop's lanes busy and need the flag word of the hit; spread over the wave they were 14 % slower.)
-template <bool COUNT>
+// ANY (shadow walks of scenes whose objects are all opaque): a hit closer than the owner's t.tblock ends that ray's
+// search whatever else lies on its way, so it is recorded with distance bits zero - nothing beats it in the minimum,
+// every later test of the same ray fails against a far limit of zero - and the owner drops its stack.
+template <bool COUNT, bool ANY = false>
 __device__ __forceinline__ void tri_phase_coop(const TraceMem& m, Trav& t, bool pending, CoopLds* cl, TraceCount& cnt) {
     const uint32_t lane = __lane_id();
     const uint32_t bits = pending ? t.T.y : 0u;
@@ -224,6 +231,7 @@ __device__ __forceinline__ void tri_phase_coop(const TraceMem& m, Trav& t, bool 
         const V3 o = v3(__shfl(t.o.x, src), __shfl(t.o.y, src), __shfl(t.o.z, src));
         const V3 d = v3(__shfl(t.d.x, src), __shfl(t.d.y, src), __shfl(t.d.z, src));
         const float tmin = __shfl(t.tmin, src);
+        const float tblock = ANY ? __shfl(t.tblock, src) : 0.f;
         const float tmax = __uint_as_float((uint32_t)(cl->best[src] >> 32));
         if (valid) {
             uint32_t ti = tbase + k;
@@ -246,8 +254,12 @@ __device__ __forceinline__ void tri_phase_coop(const TraceMem& m, Trav& t, bool 
             if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * tmin < Tn && Tn <= absDen * tmax) {
                 // search distance only (the final one is re-evaluated in fp64, see refine_distance): the 1-ulp
                 // reciprocal saves the ten-instruction IEEE division
-                const unsigned long long key = (unsigned long long)__float_as_uint(Tn * __builtin_amdgcn_rcpf(absDen)) << 32;
-                atomicMin(&cl->best[src], key | (unsigned long long)ti);
+                if (ANY && Tn < absDen * tblock) {
+                    atomicMin(&cl->best[src], (unsigned long long)ti);
+                } else {
+                    const unsigned long long key = (unsigned long long)__float_as_uint(Tn * __builtin_amdgcn_rcpf(absDen)) << 32;
+                    atomicMin(&cl->best[src], key | (unsigned long long)ti);
+                }
             }
         }
     }
@@ -259,6 +271,13 @@ __device__ __forceinline__ void tri_phase_coop(const TraceMem& m, Trav& t, bool 
         t.tmax = __uint_as_float((uint32_t)(r >> 32));
         t.hit = (uint32_t)r;
         t.T.y = rest;
+        if (ANY && (uint32_t)(r >> 32) == 0u && t.hit != 0xffffffffu) {
+            // stopped at a surface before the end point: the search is over (no accepted distance is zero: tmin > 0)
+            t.G = make_uint2(0u, 0u);
+            t.T.y = 0u;
+            t.sp = 0;
+            t.tblock = -1.0f;
+        }
     }
 }
 
@@ -277,7 +296,7 @@ __device__ __forceinline__ void tri_phase_coop(const TraceMem& m, Trav& t, bool 
 template <bool COUNT, bool SHADOW = false, bool COOP = false>
 __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have, uint2* lds, uint32_t glane,
                                           TraceCount& cnt, CoopLds* coop = nullptr) {
-    static_assert(!(SHADOW && COOP), "shadow walks use the sequential triangle loop");
+    // (SHADOW && COOP: the any-hit form of the cooperative phase, for scenes whose objects are all opaque)
     const int tri_quorum = m.tri_quorum;
     bool descend = have && t.T.y == 0u;
     if (COUNT) {
@@ -345,7 +364,7 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
     bool can_descend = have && t.T.y == 0u && ((t.G.y & 0xff000000u) != 0u || t.sp > 0);
     int waiting = (int)__popcll(__ballot(pending));
     if (COOP) {
-        if (waiting > 0) tri_phase_coop<COUNT>(m, t, pending, coop, cnt);
+        if (waiting > 0) tri_phase_coop<COUNT, SHADOW>(m, t, pending, coop, cnt);
     } else if (waiting >= tri_quorum || (waiting > 0 && !__any(can_descend))) {
         // (lanes without a ray, whose state is stale, stay out: `bits` is zero for them)
         uint32_t bits = pending ? t.T.y : 0u;

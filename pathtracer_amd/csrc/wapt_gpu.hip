@@ -177,10 +177,15 @@ __device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, 
 
 // `target`: 0, or 1 + the index of the area light whose quad `to` was sampled on when the walk arrives
 // at that quad steeply enough for its last hit to be decided without a second look (see k_shadow).
+// Bit 31: nothing but the quad itself can be met in the last stretch before `to` (DLight::front_clear).
+#define WAPT_TARGET_CLEAR 0x80000000u
+__device__ __forceinline__ uint32_t shadow_target_steep(const DLight& L, int l) {
+    return ((uint32_t)l + 1u) | (L.front_clear ? WAPT_TARGET_CLEAR : 0u);
+}
 __device__ __forceinline__ uint32_t shadow_target(const DLight& L, int l, V3 from, V3 to) {
     if (L.type != 0) return 0u;
     V3 wi = normalized(to - from);
-    return fabsf(dot(wi, ld3(L.N))) >= 0.25f ? (uint32_t)l + 1u : 0u;
+    return fabsf(dot(wi, ld3(L.N))) >= 0.25f ? shadow_target_steep(L, l) : 0u;
 }
 
 __device__ __forceinline__ void write_shadow(const KQueues& q, uint32_t slot, V3 from, V3 to, V3 w, uint32_t pixel, uint32_t target) {
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                             float sc_ = rls * (1.0f / WAPT_PI) * ndw * rpdf;
                             wt = sc_ * (w * kd * ld3(L.Li));
                             emit = true;
-                            if (L.type == 0 && fabsf(dot(Wi, ld3(L.N))) >= 0.25f) tgt = (uint32_t)l + 1u;
+                            if (L.type == 0 && fabsf(dot(Wi, ld3(L.N))) >= 0.25f) tgt = shadow_target_steep(L, l);
                         }
                     }
                     DBG(c.pixel, "nee d=%d key=%08x emit=%d LP=(%.5f %.5f %.5f) wt=%g\n", depth, c.key, (int)emit, LP.x, LP.y, LP.z, wt.x);
@@ -906,8 +911,13 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
 template <bool COUNT, bool PLAIN, bool FOGGY = false>
 __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
-    __shared__ float4 s_stage[WAPT_BLOCK];
-    float4* stage = &s_stage[threadIdx.x & ~63u];
+    __shared__ union WaveLds {
+        float4 stage[64];
+        CoopLds coop;
+    } s_wave[WAPT_BLOCK / 64];  // (the two are used at different points of a loop trip)
+    float4* stage = s_wave[threadIdx.x >> 6].stage;
+    CoopLds* coop = &s_wave[threadIdx.x >> 6].coop;
+    constexpr bool COOP = PLAIN && WAPT_SHADOW_COOP;
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = min(q.cnt[CNT_S], q.capS);
     TraceCount tc = {};
@@ -923,6 +933,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
     float ABl = 0.f, d = 0.f;
     int cur = global_m, it = 0;
     uint32_t task = 0, target = 0;
+    bool cut = false;  // the search of this walk ends short of B (see below)
     V3 cw = v3(0, 0, 0);  // weight and pixel of the task (read with it: a read at the walk's end is a memory round trip
     uint32_t cpixel = 0;  // that the whole wave waits for, 4 % of the kernel)
     for (;;) {
@@ -944,6 +955,8 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             it = 0;
             task = idx;
             target = f2u(b.w);
+            cut = PLAIN && sc.fast_shadow && (target & WAPT_TARGET_CLEAR) != 0u;
+            target &= ~WAPT_TARGET_CLEAR;
             have_task = ABl > 0.f;
         }
         if (have_task && !have_ray) {
@@ -953,7 +966,10 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             // the fp32 error of search distances (about 2e-5 relative); the walk's own tests below use the
             // refined distance and the reference's thresholds.
             float rest = ABl - d, margin = 0.002f + 1e-4f * ABl;
-            trav_begin(t, t.o, t.d, WAPT_TRACE_BIAS, rest + margin);
+            // A walk that ends on the quad of a light with nothing in front of it (PLAIN scenes): the quad is the only
+            // surface within the margin of B, and it is met at B (cpp:775: arrived), so the search ends short of it -
+            // whatever it finds blocks, and the nodes and triangles around the light are never visited.
+            trav_begin(t, t.o, t.d, WAPT_TRACE_BIAS, cut ? rest - margin : rest + margin);
             // (never negative here: a negative value is how the search reports that it stopped at an opaque surface; with a
             //  remaining way shorter than the margin the stop simply never fires)
             t.tblock = sc.fast_shadow ? fmaxf(rest - margin, 0.0f) : -1.0f;  // (the step-by-step path searches for the closest hit)
@@ -964,14 +980,28 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
         //  rest of the loop body does nothing then)
         if (!__any(have_task) && feed.exhausted()) break;
         bool lit = false;
-        if (trav_step<COUNT, true>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc)) {
+        if (trav_step<COUNT, true, COOP>(sc.tm, t, have_ray, &s_stack[threadIdx.x], glane, tc, coop)) {
             have_ray = false;
             const uint32_t tri = t.hit;
             bool blocked = sc.fast_shadow && t.tblock < 0.f;  // (1)
             bool general = false;
-            if (PLAIN) {
+            if (PLAIN && cut) {
+                lit = !blocked && tri == 0xffffffffu;
+                blocked = !lit;
+                if (FOGGY && lit) V = attenuation(sc.mats[global_m], ABl);
+            } else if (PLAIN) {
                 if (!blocked) {
-                    const bool at_target = tri != 0xffffffffu && target != 0u && (t.hflag >> WAPT_TRI_OBJ_SHIFT) == target - 1u;
+                    bool at_target = false;
+                    if (COOP) {
+                        // (the cooperative phase does not bring the hit triangle's flag word along: the quad of the
+                        //  sampled light is known by its two triangles)
+                        if (tri != 0xffffffffu && target != 0u) {
+                            const DLight& TL = sc.lights[target - 1u];
+                            at_target = tri == (uint32_t)TL.tri0 || tri == (uint32_t)TL.tri1;
+                        }
+                    } else {
+                        at_target = tri != 0xffffffffu && target != 0u && (t.hflag >> WAPT_TRI_OBJ_SHIFT) == target - 1u;
+                    }
                     // FOGGY (the global medium attenuates): the part of the way it attenuates - all of it unless the walk
                     // ends on a back face, whose last stretch the step-by-step path takes through the object's clear inside
                     float seg = ABl;
@@ -1643,15 +1673,6 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     }
     HIPCHK_S(hipMalloc(&s->d_mats, mats.size() * sizeof(DMaterial)));
     HIPCHK_S(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
-    std::vector<DLight> lights((size_t)std::max(desc->n_lights, 1));
-    for (int i = 0; i < desc->n_lights; i++) lights[i] = to_device(desc->lights[i]);
-    HIPCHK_S(hipMalloc(&s->d_lights, lights.size() * sizeof(DLight)));
-    HIPCHK_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
-    s->n_lights = desc->n_lights;
-    if (desc->n_lights > 0)
-        hipLaunchKernelGGL(k_light_tris, dim3((unsigned)((s->n_tris + 255) / 256)), dim3(256), 0, s->stream, (const float4*)s->d_tris,
-                           (uint32_t)s->n_tris, desc->n_lights, (DLight*)s->d_lights);
-
     // longest possible segment: everything lives inside the ball around the world
     // centre that holds the world sphere, the geometry and the camera
     {
@@ -1667,6 +1688,56 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
         rb = std::max(rb, std::sqrt(dx * dx + dy * dy + dz * dz));
         s->max_segment = (float)(2.0 * rb * 1.001);
     }
+
+    std::vector<DLight> lights((size_t)std::max(desc->n_lights, 1));
+    for (int i = 0; i < desc->n_lights; i++) lights[i] = to_device(desc->lights[i]);
+    // DLight::front_clear.  A shadow search resolves distances to about 0.002 + 1e-4 x its length; a walk towards a point
+    // B on the quad may end its search that far short of B if nothing but the quad can be met there.  Walks arrive from
+    // the front (lights.cpp:91 rejects the rest) at |cos| >= 0.25, so a surface that stays on or behind the quad's plane
+    // (to within 2.5e-4: TRACE_BIAS x 0.25) is met after B or with it, which counts as arrived (cpp:775).  The light is
+    // clear if every other object's triangle near the quad (boxes within the margin) is such a surface.
+    {
+        const double reach = 0.002 + 1e-4 * (double)s->max_segment + 1e-3;
+        const uint64_t budget = 4000000000ull;  // triangle-light pairs looked at (a scene with thousands of lights skips this)
+        int n_area = 0;
+        for (int i = 0; i < desc->n_lights; i++) n_area += desc->lights[i].type == 0;
+        const char* cut_env = getenv("WAPT_SHADOW_CUT");  // WAPT_SHADOW_CUT=0: every walk searches up to its end point
+        if (n_area > 0 && (uint64_t)n_area * desc->n_tris <= budget && !(cut_env && cut_env[0] == '0')) {
+            for (int l = 0; l < desc->n_lights; l++) {
+                if (desc->lights[l].type != 0) continue;
+                const DLight& L = lights[l];
+                double lo[3], hi[3];
+                for (int a = 0; a < 3; a++) {
+                    const double c[4] = {L.P[a], (double)L.P[a] + L.U[a], (double)L.P[a] + L.V[a], (double)L.P[a] + L.U[a] + L.V[a]};
+                    lo[a] = std::min(std::min(c[0], c[1]), std::min(c[2], c[3])) - reach;
+                    hi[a] = std::max(std::max(c[0], c[1]), std::max(c[2], c[3])) + reach;
+                }
+                bool clear = std::isfinite(L.N[0]) && std::isfinite(L.N[1]) && std::isfinite(L.N[2]);
+                for (uint64_t t = 0; t < desc->n_tris && clear; t++) {
+                    if (desc->tri_obj[t] == l) continue;
+                    const float* v = desc->tri_verts + 9 * t;
+                    bool overlap = true;
+                    for (int a = 0; a < 3 && overlap; a++) {
+                        const double tlo = std::min(std::min(v[a], v[3 + a]), v[6 + a]), thi = std::max(std::max(v[a], v[3 + a]), v[6 + a]);
+                        overlap = tlo <= hi[a] && thi >= lo[a];
+                    }
+                    if (!overlap) continue;
+                    for (int k = 0; k < 3 && clear; k++) {
+                        const double sd = ((double)v[3 * k] - L.P[0]) * L.N[0] + ((double)v[3 * k + 1] - L.P[1]) * L.N[1] +
+                                          ((double)v[3 * k + 2] - L.P[2]) * L.N[2];
+                        if (!(sd <= 2.5e-4)) clear = false;
+                    }
+                }
+                lights[l].front_clear = clear ? 1 : 0;
+            }
+        }
+    }
+    HIPCHK_S(hipMalloc(&s->d_lights, lights.size() * sizeof(DLight)));
+    HIPCHK_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    s->n_lights = desc->n_lights;
+    if (desc->n_lights > 0)
+        hipLaunchKernelGGL(k_light_tris, dim3((unsigned)((s->n_tris + 255) / 256)), dim3(256), 0, s->stream, (const float4*)s->d_tris,
+                           (uint32_t)s->n_tris, desc->n_lights, (DLight*)s->d_lights);
 
     hipDeviceProp_t prop;
     HIPCHK_S(hipGetDeviceProperties(&prop, device));

@@ -159,3 +159,53 @@ def test_two_scenes_rendered_from_two_threads_at_once():
     assert not err, err
     for a, b in zip(alone, out):
         np.testing.assert_allclose(b, a, rtol=2e-4, atol=1e-6)
+
+
+def _sheet(y, x0=150.0, x1=400.0, z0=150.0, z1=400.0):
+    """A horizontal sheet (normal -y: faces the floor, like the light) spanning more than the light's quad."""
+    v = np.array([[x0, y, z0], [x1, y, z0], [x1, y, z1], [x0, y, z1]], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    return meshes.expand(v, f)
+
+
+@pytest.mark.parametrize("gap", [0.01, 0.04, 2.0])
+def test_an_opaque_sheet_just_in_front_of_the_light(gap, monkeypatch):
+    """Shadow walks that end on a light's quad stop searching a little short of it when nothing lies in front of the
+    quad.  Here something does: an opaque sheet `gap` below the middle of the light, closer than the margin of a
+    search (0.002 + 1e-4 |AB|) for the first two gaps.  The scene must fall back to the full search: same image as the
+    step-by-step path and as the checker.  (A gap below TRACE_BIAS is left out: whether a walk then "arrives" through
+    the sheet hangs on the last bits of single-precision distances in the reference itself.)"""
+    sc = box_scene([area_light(**scenes.LIGHT)], res=(32, 32), extra=[_sheet(550.0 - gap, 240.0, 310.0, 240.0, 310.0)],
+                   extra_mats=[material("diffuse", (0.5, 0.5, 0.5))])
+    fast, st_fast = gpu_render(sc, 8, seed=2)
+    same_seed_check(sc, 8, seed=2)
+    monkeypatch.setenv("WAPT_GENERAL_SHADOW", "1")
+    general, st_gen = gpu_render(sc, 8, seed=2)
+    np.testing.assert_allclose(fast, general, rtol=2e-4, atol=1e-6)
+    assert st_fast.rays == st_gen.rays
+
+
+@pytest.mark.parametrize("gap", [0.0015, 0.01, 0.08])
+def test_a_transparent_sheet_within_the_search_margin_of_the_light(gap, monkeypatch):
+    """A non-opaque (scattering, flag-less sss) sheet close below the light: the walk passes it and its continued
+    segment is shorter than the margin of the search (0.002 + 1e-4 |AB|).  The walk must still arrive: the fast
+    path against the step-by-step path and the checker."""
+    sss = material("sss", kt=(1.0, 1.0, 1.0), sa=(0.01, 0.01, 0.01), ss=(0.0, 0.0, 0.0))
+    sc = box_scene([area_light(**scenes.LIGHT)], res=(32, 32), extra=[_sheet(550.0 - gap)], extra_mats=[sss])
+    fast, st_fast = gpu_render(sc, 8, seed=4)
+    assert fast.mean() > 0.05  # lit through the sheet
+    same_seed_check(sc, 8, seed=4, frac=0.99)
+    monkeypatch.setenv("WAPT_GENERAL_SHADOW", "1")
+    general, st_gen = gpu_render(sc, 8, seed=4)
+    np.testing.assert_allclose(fast, general, rtol=2e-4, atol=1e-6)
+    assert st_fast.rays == st_gen.rays
+
+
+def test_walks_that_stop_short_of_a_clear_light_equal_full_searches(monkeypatch):
+    """WAPT_SHADOW_CUT=0 makes every walk search up to its end point: same image, same number of queries."""
+    sc = scenes.cornell(res=(96, 96), spheres=True, sphere_segments=(16, 32))
+    cut, st_cut = gpu_render(sc, 16, seed=6)
+    monkeypatch.setenv("WAPT_SHADOW_CUT", "0")
+    full, st_full = gpu_render(sc, 16, seed=6)
+    np.testing.assert_allclose(cut, full, rtol=2e-4, atol=1e-6)
+    assert st_cut.rays == st_full.rays

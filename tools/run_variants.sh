@@ -4,7 +4,7 @@ shopt -s nullglob
 out=gpurun_out/variants; mkdir -p $out
 run() { # name, env...
   name=$1; shift
-  env "$@" timeout -k 10 200 python bench.py --spp ${SPP:-64} --steps 2 --no-cpu-baseline > $out/$name.json 2> $out/$name.err || { echo "$name FAILED"; tail -3 $out/$name.err; return 1; }
+  env "$@" timeout -k 10 200 python bench.py --spp ${SPP:-256} --steps ${STEPS:-3} --no-cpu-baseline --no-pmc > $out/$name.json 2> $out/$name.err || { echo "$name FAILED"; tail -3 $out/$name.err; return 1; }
   python - "$name" $out/$name.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]); r=d.get("roofline",{})
