@@ -24,6 +24,13 @@
 #include <stdint.h>
 #include <vector>
 
+// Bytes from one node record to the next: 80 (packed) or 128 (one record per 128-byte line of L2 / HBM: a packed
+// record straddles two lines in five cases of eight, which costs nothing while the tree sits in cache and a second
+// line fetch per visit where it does not).
+#ifndef WAPT_NODE_BYTES
+#define WAPT_NODE_BYTES 80
+#endif
+
 struct Bvh8Node {
     float p[3];
     uint8_t e[3];
@@ -34,8 +41,11 @@ struct Bvh8Node {
     uint8_t qlo_x[8], qlo_y[8];
     uint8_t qlo_z[8], qhi_x[8];
     uint8_t qhi_y[8], qhi_z[8];
+#if WAPT_NODE_BYTES > 80
+    uint8_t pad[WAPT_NODE_BYTES - 80];
+#endif
 };
-static_assert(sizeof(Bvh8Node) == 80, "node must be 80 bytes");
+static_assert(sizeof(Bvh8Node) == WAPT_NODE_BYTES && WAPT_NODE_BYTES % 16 == 0, "node record size");
 
 struct Bvh8Tri {
     float v0[3];

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "bvh8.h"
 #include "device_math.h"
 
 #define WAPT_BLOCK 256
@@ -183,6 +184,7 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
 #ifndef WAPT_SHADOW_COOP
 #define WAPT_SHADOW_COOP 0
 #endif
+
 struct CoopLds {
     unsigned long long best[64];
     uint16_t items[64 * WAPT_COOP_PER_LANE];
@@ -334,7 +336,7 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
         uint32_t rel = __popc(hits_imask & 0xffu & ((1u << slot) - 1u));
         uint32_t ni = t.G.x + rel;
         WAPT_CHECK_IDX(ni, m.n_nodes, "node");
-        const uint4* np = m.nodes + (uint32_t)(ni * 5u);  // (32-bit index arithmetic: a 64-bit multiply runs at quarter rate)
+        const uint4* np = m.nodes + (uint32_t)(ni * (uint32_t)(WAPT_NODE_BYTES / 16));  // (32-bit index arithmetic: a 64-bit multiply runs at quarter rate)
         uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
         if (COUNT) cnt.nodes++;
 

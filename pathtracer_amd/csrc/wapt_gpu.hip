@@ -1513,7 +1513,7 @@ DCamera to_device(const wapt_camera& c) {
     return d;
 }
 
-const uint64_t WAPT_MAX_TRIS = 0xffffffffull / 3, WAPT_MAX_NODES = 0xffffffffull / 5;
+const uint64_t WAPT_MAX_TRIS = 0xffffffffull / 3, WAPT_MAX_NODES = 0xffffffffull / (WAPT_NODE_BYTES / 16);
 
 int validate_desc(const wapt_scene_desc* d) {
     if (!d) return wapt_fail(WAPT_E_INVALID, "null scene description");

@@ -2,7 +2,7 @@
 # Short benchmark of the other BASELINE scenes (reduced spp), one JSON file per scene under gpurun_out/scenes/.
 out=gpurun_out/scenes; mkdir -p $out
 run() { # scene spp
-  timeout -k 10 300 python bench.py --scene $1 --spp $2 --steps 1 --warmup 1 --no-cpu-baseline > $out/$1.json 2> $out/$1.err || { echo "$1 FAILED"; tail -5 $out/$1.err; return 1; }
+  timeout -k 10 300 python bench.py --scene $1 --spp $2 --steps 1 --warmup 1 --no-cpu-baseline --no-pmc > $out/$1.json 2> $out/$1.err || { echo "$1 FAILED"; tail -5 $out/$1.err; return 1; }
   python - $1 $out/$1.json <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]); r=d.get("roofline",{})
