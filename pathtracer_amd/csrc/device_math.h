@@ -50,15 +50,22 @@ WAPT_HD float wsqrt(float x) {
 #endif
 }
 WAPT_HD float mag(V3 a) { return wsqrt(dot(a, a)); }
+WAPT_HD V3 normalized_len(V3 a, float* len);
+// Three divisions by the same length, as the reference has them, and rounded as a division rounds: one refined
+// reciprocal for all three, then per component the steps of the hardware's division sequence (product, two
+// corrections from the exact residual) without its range scaling - the divisor is a length of scene scale.
+// 18 instructions instead of 30: the surface kernel is 4 % faster, the same-seed agreement with the CPU checker
+// is unchanged scene by scene.  (One reciprocal and three plain products would be cheaper still and move the
+// directions by an ulp: that alone lowered the agreement from 99.74 to 99.52 %.)
 WAPT_HD V3 normalized(V3 a) {
+    float m;
+    return normalized_len(a, &m);
+}
+// normalized(a) and the length it divides by
+WAPT_HD V3 normalized_len(V3 a, float* len) {
     float m = mag(a);
+    *len = m;
 #if defined(__HIP_DEVICE_COMPILE__)
-    // Three divisions by the same length, as the reference has them, and rounded as a division rounds: one refined
-    // reciprocal for all three, then per component the steps of the hardware's division sequence (product, two
-    // corrections from the exact residual) without its range scaling - the divisor is a length of scene scale.
-    // 18 instructions instead of 30: the surface kernel is 4 % faster, the same-seed agreement with the CPU checker
-    // is unchanged scene by scene.  (One reciprocal and three plain products would be cheaper still and move the
-    // directions by an ulp: that alone lowered the agreement from 99.74 to 99.52 %.)
     float r = __builtin_amdgcn_rcpf(m);
     r = fmaf(fmaf(-m, r, 1.0f), r, r);
     float qx = a.x * r, qy = a.y * r, qz = a.z * r;

@@ -182,26 +182,29 @@ __device__ __forceinline__ void push_radiance(const KQueues& q, int depth_next, 
 __device__ __forceinline__ uint32_t shadow_target_steep(const DLight& L, int l) {
     return ((uint32_t)l + 1u) | (L.front_clear ? WAPT_TARGET_CLEAR : 0u);
 }
-__device__ __forceinline__ uint32_t shadow_target(const DLight& L, int l, V3 from, V3 to) {
+// `wi`: unit direction from the walk's start to its end point
+__device__ __forceinline__ uint32_t shadow_target(const DLight& L, int l, V3 wi) {
     if (L.type != 0) return 0u;
-    V3 wi = normalized(to - from);
     return fabsf(dot(wi, ld3(L.N))) >= 0.25f ? shadow_target_steep(L, l) : 0u;
 }
 
-__device__ __forceinline__ void write_shadow(const KQueues& q, uint32_t slot, V3 from, V3 to, V3 w, uint32_t pixel, uint32_t target) {
+// A shadow walk from `from` along the unit vector `dir` over the distance `len` (to the sampled light point).
+__device__ __forceinline__ void write_shadow(const KQueues& q, uint32_t slot, V3 from, V3 dir, float len, V3 w, uint32_t pixel,
+                                             uint32_t target) {
     if (slot >= q.capS) {
         atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
         return;
     }
     q.SA[slot] = make_float4(from.x, from.y, from.z, u2f(pixel));
-    q.SB[slot] = make_float4(to.x, to.y, to.z, u2f(target));
-    q.SC[slot] = make_float4(w.x, w.y, w.z, 0.f);
+    q.SB[slot] = make_float4(dir.x, dir.y, dir.z, u2f(target));
+    q.SC[slot] = make_float4(w.x, w.y, w.z, len);
 }
 
-__device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from, V3 to, V3 w, uint32_t pixel, uint32_t target) {
+__device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from, V3 dir, float len, V3 w, uint32_t pixel,
+                                            uint32_t target) {
     pred = pred && !is_zero(w);
     uint32_t slot = block_push(&q.cnt[CNT_S], pred);
-    if (pred) write_shadow(q, slot, from, to, w, pixel, target);
+    if (pred) write_shadow(q, slot, from, dir, len, w, pixel, target);
 }
 
 __device__ __forceinline__ void write_probe(const KQueues& q, uint32_t slot, V3 o, V3 dir, V3 w, uint32_t pixel, uint32_t info, int medium) {
@@ -548,14 +551,15 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
         for (int l = 0; l < sc.n_lights; l++) {
             for (int s = 0; s < lsamples; s++) {
                 bool emit = false;
-                V3 LP = v3(0, 0, 0), wt = v3(0, 0, 0);
+                V3 LP = v3(0, 0, 0), wt = v3(0, 0, 0), Wi = v3(0, 0, 1);
+                float Wl = 0.f;
                 uint32_t tgt = 0u;
                 if (lambert) {
                     uint32_t dim = WAPT_DIM_NEE + 2u * (uint32_t)(l * lsamples + s);
                     float rpdf;
                     const DLight& L = sc.lights[l];
                     if (light_sample(L, c.P, N1f, true, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &LP, &rpdf)) {
-                        V3 Wi = normalized(LP - c.P);
+                        Wi = normalized_len(LP - c.P, &Wl);
                         float ndw = dot(Wi, N1f);
                         if (!(ndw < 0.0f)) {
                             float sc_ = rls * (1.0f / WAPT_PI) * ndw * rpdf;
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                     }
                     DBG(c.pixel, "nee d=%d key=%08x emit=%d LP=(%.5f %.5f %.5f) wt=%g\n", depth, c.key, (int)emit, LP.x, LP.y, LP.z, wt.x);
                 }
-                push_shadow(q, emit, c.P, LP, wt, c.pixel, tgt);
+                push_shadow(q, emit, c.P, Wi, Wl, wt, c.pixel, tgt);
             }
         }
         // children: hsamples uniform hemisphere directions of a Lambert event (no emission at the next
@@ -800,9 +804,11 @@ __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScen
                                 emit = !is_zero(wt);
                             }
                         }
-                        const uint32_t tgt = emit ? shadow_target(L, l, S, LP) : 0u;
+                        float Wl = 0.f;
+                        const V3 Wi = normalized_len(LP - S, &Wl);
+                        const uint32_t tgt = emit ? shadow_target(L, l, Wi) : 0u;
                         if (k > 0) {
-                            push_shadow(q, emit, S, LP, wt, c.pixel, tgt);
+                            push_shadow(q, emit, S, Wi, Wl, wt, c.pixel, tgt);
                             continue;
                         }
                         // first light sample, the sphere-sampling probe and (with the first light) the child
@@ -821,7 +827,7 @@ __global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScen
                         const bool preds[3] = {emit, probe && reachable, cemit && !child_done};
                         uint32_t slots[3];
                         block_push3(counters, preds, slots);
-                        if (preds[0]) write_shadow(q, slots[0], S, LP, wt, c.pixel, tgt);
+                        if (preds[0]) write_shadow(q, slots[0], S, Wi, Wl, wt, c.pixel, tgt);
                         if (preds[1]) write_probe(q, slots[1], S, pdir, pw, c.pixel, (uint32_t)l, medium);
                         if (preds[2]) write_radiance(q, depth + 1, slots[2], S, cdir, cbeta, c.pixel, cinfo, ckey);
                         child_done = true;
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
     V3 V = v3(1, 1, 1);
     float ABl = 0.f, d = 0.f;
     int cur = global_m, it = 0;
-    uint32_t task = 0, target = 0;
+    uint32_t target = 0;
     bool cut = false;  // the search of this walk ends short of B (see below)
     V3 cw = v3(0, 0, 0);  // weight and pixel of the task (read with it: a read at the walk's end is a memory round trip
     uint32_t cpixel = 0;  // that the whole wave waits for, 4 % of the kernel)
@@ -944,16 +950,13 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             float4 w4s = q.SC[idx];
             cw = v3(w4s.x, w4s.y, w4s.z);
             cpixel = f2u(a.w);
-            V3 A = v3(a.x, a.y, a.z);
-            V3 AB = v3(b.x, b.y, b.z) - A;
-            ABl = sqrtf(dot(AB, AB));  // (same value as mag(); the library sequence measured 2.5 % faster in this kernel)
-            t.o = A;
-            t.d = (1.0f / ABl) * AB;
+            ABl = w4s.w;  // (direction and length come with the task: the kernel that sampled the light point had them)
+            t.o = v3(a.x, a.y, a.z);
+            t.d = v3(b.x, b.y, b.z);
             V = v3(1.f, 1.f, 1.f);
             d = 0.f;
             cur = global_m;
             it = 0;
-            task = idx;
             target = f2u(b.w);
             cut = PLAIN && sc.fast_shadow && (target & WAPT_TARGET_CLEAR) != 0u;
             target &= ~WAPT_TARGET_CLEAR;
@@ -1031,12 +1034,8 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                 } else if (sc.fast_shadow && tri == 0xffffffffu) {
                     // (2) in a medium that attenuates: what is left of the way to B, through the medium the walk is in
                     // (the last step of the general path, cpp:764-775)
-                    float seg = ABl;
-                    if (it > 0) {
-                        WAPT_CHECK_IDX(task, q.capS, "shadow task (re-read of B)");
-                        float4 b = q.SB[task];
-                        seg = mag(v3(b.x, b.y, b.z) - t.o);
-                    }
+                    // (on a continued walk the start of the segment lies on the way, d from A: |B - P0| = |AB| - d)
+                    const float seg = ABl - d;
                     WAPT_CHECK_IDX(cur, sc.n_objects + 1, "medium of a shadow walk");
                     V = V * attenuation(sc.mats[cur], seg);
                     lit = true;
@@ -1059,6 +1058,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                 int obj = -1;
                 float seg;   // |P1 - P0|
                 V3 hp = point_at(P0, tmax, ABn);
+                const float d0 = d;  // distance from A to the start of this segment
                 if (tri != 0xffffffffu) d += mag(hp - P0);
                 else d = 2.0f * ABl;
                 if (d <= ABl + WAPT_TRACE_BIAS) {
@@ -1080,12 +1080,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                 } else {
                     // the segment ends at B; on the first segment P0 is A and |B - A| is ABl itself
                     P1 = P0;
-                    seg = ABl;
-                    if (it > 0) {
-                        WAPT_CHECK_IDX(task, q.capS, "shadow task (re-read of B, general path)");
-                        float4 b = q.SB[task];
-                        seg = mag(v3(b.x, b.y, b.z) - P0);
-                    }
+                    seg = ABl - d0;  // |B - P0|: P0 lies on the way, d0 from A (on the first segment P0 is A and d0 is 0)
                     d = ABl;
                 }
                 if (!blocked) {
@@ -1109,7 +1104,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             pixel = cpixel;
             WAPT_CHECK_IDX(pixel, (uint32_t)(sc.cam.resI * sc.cam.resJ), "pixel of a shadow task");
             contrib = cw * V;
-            DBG(pixel, "shadow task=%u lit V=%g w=%g d=%.6f ABl=%.6f\n", task, V.x, cw.x, d, ABl);
+            DBG(pixel, "shadow lit V=%g w=%g d=%.6f ABl=%.6f\n", V.x, cw.x, d, ABl);
         }
         wave_add_rgb(q.sum, stage, lit, pixel, contrib);
     }
