@@ -120,3 +120,34 @@ def test_abort_ends_an_iteration_and_leaves_the_average():
         r.close()
     finally:
         c.close()
+
+
+def test_a_progressive_handle_outlives_its_scene_safely():
+    """Closing the content first cuts its renderers' progressive handles loose: every later call on such a handle is
+    an error return (no access to the freed scene), and closing the renderer afterwards is fine."""
+    c = renderer.wa_content(small_scene())
+    r = renderer.udp_renderer(c, 2, seed=1)
+    r.reset()
+    r.render()
+    c.close()
+    with pytest.raises(capi.WaptError) as e:
+        r.render()
+    assert "destroyed" in str(e.value)
+    with pytest.raises(capi.WaptError):
+        r.reset()
+    with pytest.raises(capi.WaptError):
+        r.setRegion(0, 4, 0, 4)
+    r.close()
+    r.close()
+
+
+def test_profile_is_refused_not_ignored_on_the_progressive_interface():
+    c = renderer.wa_content(small_scene())
+    try:
+        r = renderer.udp_renderer(c, 2, seed=1)
+        r.reset()
+        with pytest.raises(ValueError):
+            r.render(profile=True)
+        r.close()
+    finally:
+        c.close()

@@ -116,6 +116,26 @@ def test_waff_errors(scene_dir):
         Scene.from_waff(str(bad))
 
 
+def test_a_mesh_header_that_promises_more_than_the_file_holds_is_refused(scene_dir):
+    """The counts of a .fast header size the arrays: a count of 0x7fffffff must be an I/O error, not a 32 GiB
+    allocation (and never an exception through the C ABI)."""
+    from pathtracer_amd import capi
+    raw = bytearray(open(scene_dir / "ball.fast", "rb").read())
+    for which in (0, 4):
+        bad = bytearray(raw)
+        bad[which:which + 4] = struct.pack("<i", 0x7fffffff)
+        open(scene_dir / "ball.fast", "wb").write(bad)
+        h = C.c_void_p()
+        cwd = os.getcwd()
+        os.chdir(scene_dir)
+        try:
+            rc = capi.wapt_waff_load(os.fsencode(str(scene_dir / "test.waff")), C.byref(h))
+        finally:
+            os.chdir(cwd)
+        assert rc == 2 and not h.value, capi.wapt_last_error()  # WAPT_E_IO
+        assert b"truncated" in capi.wapt_last_error()
+
+
 def test_obj_reader_quads_negative_indices_and_first_shape_only(tmp_path):
     from pathtracer_amd import capi
     (tmp_path / "q.obj").write_text("# quad + later shape\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\n"
