@@ -9,7 +9,8 @@ are summed onto rank 0 with one RCCL reduce, and rank 0 scales the sum to mean r
 built and uploaded before the timed region; inputs are resident in HBM when timing starts.
 
 Work per step
-  N = 1 (default)       256 spp: the single-GPU configuration of BASELINE.json (configs[1]).
+  N = 1 (default)       256 spp: the single-GPU configuration of BASELINE.json (configs[1]).  The queues hold 256 spp
+                        of a 1080p frame, so a 1024-spp image on one GPU is four such steps at the same rate.
   N > 1 (default)       the target's own sharding: ONE image of --total-spp samples (default 1024), rank r renders
                         the contiguous block sample_range(1024, r, N) of global sample indices ("scaling": "strong").
   --spp S               S samples per pixel PER GPU instead (the image has N*S samples; "scaling": "weak").
@@ -158,10 +159,9 @@ def main():
     if args.spp is not None and args.total_spp is not None:
         ap.error("--spp and --total-spp exclude each other")
     if args.spp is None and args.total_spp is None:
-        if world == 1:
-            args.spp = 256
-        else:
-            args.total_spp = 1024
+        # one GPU: the single-GPU configuration (256 spp; a 1024-spp image is four such steps at the same rate);
+        # more: the target's 1024-spp image, spp / N per GPU
+        args.total_spp = 256 if world == 1 else 1024
     if args.total_spp is not None:
         total_spp = args.total_spp
         begin, count = distributed.sample_range(total_spp, rank, world)

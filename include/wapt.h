@@ -209,10 +209,11 @@ int wapt_write_bmp(const char* path, int32_t w, int32_t h, const float* fb);
  * scene, BVH and work queues to GPU `device`. */
 int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wapt_scene** out);
 /* Same with the BVH builder chosen by the caller.  The reference has one builder (Embree's, on the
- * CPU, inside rtcCommitScene); here the binned-SAH host builder gives the faster tree and the device
- * builder (Morton-code radix tree collapsed to 8-wide nodes on the GPU) the faster build: about a
- * second instead of tens of seconds for 5e7 triangles.  AUTO takes the device builder from 2^24
- * triangles on (WAPT_BVH_BUILDER=host|device and WAPT_DEVICE_BUILD_MIN_TRIS override). */
+ * CPU, inside rtcCommitScene).  Here: a device builder (Morton order, parallel locally-ordered
+ * clustering, collapse to 8-wide nodes on the GPU: 0.2 s for 5.6e7 triangles) and a host builder
+ * (binned SAH, threaded: 26 s for the same).  AUTO takes the device builder, whose trees trace as
+ * fast or faster on all but one of the benchmark scenes (WAPT_BVH_BUILDER=host|device overrides;
+ * WAPT_DEVICE_BVH=lbvh selects the older radix-tree construction inside the device builder). */
 enum { WAPT_BUILDER_AUTO = 0, WAPT_BUILDER_HOST_SAH = 1, WAPT_BUILDER_DEVICE_LBVH = 2 };
 int wapt_scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_t builder, wapt_scene** out);
 void wapt_scene_destroy(wapt_scene* s);

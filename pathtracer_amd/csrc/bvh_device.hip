@@ -5,18 +5,23 @@
 // default; for tens of millions of triangles it takes tens of seconds, and this builder takes about one:
 //   1. triangle boxes and centroid bounds                       (k_prim, k_bounds)
 //   2. 63-bit Morton codes of the centroids, radix sort         (k_morton, rocPRIM)
-//   3. binary radix tree over the sorted codes (Karras 2012)    (k_hierarchy)
-//   4. boxes of the inner nodes, bottom-up                      (k_refit)
-//   5. collapse to 8-wide nodes level by level, with the same child-opening rule, slot assignment and
+//   3. binary tree over the sorted order: parallel locally-ordered clustering (Meister and Bittner 2018) - every
+//      cluster looks for the neighbour within a window of the current order whose union with it has the smallest
+//      surface area, mutual choices merge, the survivors are compacted, until one cluster is left
+//      (k_ploc_nearest, k_ploc_merge, k_ploc_compact); WAPT_DEVICE_BVH=lbvh selects the older, faster and
+//      lower-quality binary radix tree over the codes (Karras 2012: k_hierarchy, boxes bottom-up in k_refit)
+//   4. collapse to 8-wide nodes level by level, with the same child-opening rule, slot assignment and
 //      conservative quantisation as the host builder; leaves are subtrees of at most 3 triangles   (k_collapse)
 // The result lives in device memory in the layout the traversal kernels read.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -201,6 +206,108 @@ __device__ __forceinline__ uint32_t ref_count(const Tree2& T, uint32_t r) { retu
 __device__ __forceinline__ uint32_t ref_first(const Tree2& T, uint32_t r) { return (r & LEAF) ? (r & ~LEAF) : T.first[r]; }
 __device__ __forceinline__ Box6 ref_box(const Tree2& T, uint32_t r) { return (r & LEAF) ? T.tbox[T.sorted[r & ~LEAF]] : T.ibox[r]; }
 
+// The (at most three) triangles under a small subtree, as indices into the sorted order.
+__device__ __forceinline__ uint32_t ref_gather(const Tree2& T, uint32_t r, uint32_t out[3]) {
+    if (r & LEAF) {
+        out[0] = r & ~LEAF;
+        return 1u;
+    }
+    uint32_t n = 0;
+    const uint32_t c[2] = {T.left[r], T.right[r]};
+    for (int s = 0; s < 2; s++) {
+        if (c[s] & LEAF) {
+            if (n < 3u) out[n] = c[s] & ~LEAF;
+            n++;
+        } else {  // (a subtree of three triangles has at most one inner child, whose children are leaves)
+            const uint32_t g[2] = {T.left[c[s]], T.right[c[s]]};
+            for (int k = 0; k < 2; k++) {
+                if (n < 3u) out[n] = g[k] & ~LEAF;
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
+// ---- parallel locally-ordered clustering ----------------------------------------------------------------------
+
+// nn[i]: the cluster within `radius` positions of i whose union with cluster i has the smallest surface area
+// (ties go to the partner by position i ^ 1, else to the lower position).
+// radius 0: neighbours are paired by position (2k with 2k+1) - the safety net for a round that merged next to nothing.
+__global__ void k_ploc_nearest(const Box6* __restrict__ cbox, uint32_t m, int radius, uint32_t* __restrict__ nn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    if (radius == 0) {
+        const uint32_t j = i ^ 1u;
+        nn[i] = j < m ? j : i;
+        return;
+    }
+    const Box6 b = cbox[i];
+    float best = FLT_MAX;
+    uint32_t bj = i;
+    const long long lo = max((long long)i - radius, 0ll), hi = min((long long)i + radius, (long long)m - 1);
+    for (long long j = lo; j <= hi; j++) {
+        if (j == (long long)i) continue;
+        Box6 u = cbox[j];
+        box_grow(u, b);
+        const float a = box_area(u);
+        // (equal areas: the partner by position wins, so that a run of indistinguishable clusters - coincident
+        //  triangles - pairs up 2k with 2k+1 instead of all choosing the same neighbour)
+        if (a < best || (a == best && (uint32_t)j == (i ^ 1u))) {
+            best = a;
+            bj = (uint32_t)j;
+        }
+    }
+    nn[i] = bj;
+}
+
+// Mutual nearest neighbours become one cluster (a new inner node) at the lower of the two positions.
+__global__ void k_ploc_merge(const uint32_t* __restrict__ C, const Box6* __restrict__ cbox, const uint32_t* __restrict__ nn, uint32_t m,
+                             uint32_t* __restrict__ left, uint32_t* __restrict__ right, uint32_t* __restrict__ count, Box6* __restrict__ ibox,
+                             uint32_t* __restrict__ node_counter, uint32_t* __restrict__ outC, Box6* __restrict__ outBox,
+                             uint32_t* __restrict__ keep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    if (mutual && i > j) {
+        keep[i] = 0u;
+        return;
+    }
+    keep[i] = 1u;
+    if (!mutual) {
+        outC[i] = C[i];
+        outBox[i] = cbox[i];
+        return;
+    }
+    const uint32_t a = C[i], b = C[j];
+    const uint32_t idx = atomicAdd(node_counter, 1u);
+    left[idx] = a;
+    right[idx] = b;
+    count[idx] = ((a & LEAF) ? 1u : count[a]) + ((b & LEAF) ? 1u : count[b]);
+    Box6 u = cbox[i];
+    box_grow(u, cbox[j]);
+    ibox[idx] = u;
+    outC[i] = idx;
+    outBox[i] = u;
+}
+
+__global__ void k_ploc_compact(const uint32_t* __restrict__ inC, const Box6* __restrict__ inBox, const uint32_t* __restrict__ keep,
+                               const uint32_t* __restrict__ pos, uint32_t m, uint32_t* __restrict__ C, Box6* __restrict__ cbox) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || !keep[i]) return;
+    C[pos[i]] = inC[i];
+    cbox[pos[i]] = inBox[i];
+}
+
+__global__ void k_ploc_init(const Box6* __restrict__ tbox, const uint32_t* __restrict__ sorted, uint32_t n, uint32_t* __restrict__ C,
+                            Box6* __restrict__ cbox) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    C[i] = LEAF | i;
+    cbox[i] = tbox[sorted[i]];
+}
+
 struct CollapseOut {
     Bvh8Node* nodes;
     Bvh8Tri* tris;
@@ -354,9 +461,10 @@ __global__ void k_collapse(Tree2 T, const uint32_t* __restrict__ refs, uint32_t 
         } else {
             const uint8_t unary[4] = {0, 1, 3, 7};
             node.meta[s] = (uint8_t)((unary[c] << 5) | tri_off);
-            uint32_t f = ref_first(T, ch[k]);
+            uint32_t which[3] = {0u, 0u, 0u};
+            ref_gather(T, ch[k], which);
             for (uint32_t j = 0; j < c; j++) {
-                uint32_t t = T.sorted[f + j];
+                uint32_t t = T.sorted[which[j]];
                 const float* v = verts + 9 * (size_t)t;
                 Bvh8Tri tr;
                 for (int a = 0; a < 3; a++) {
@@ -468,16 +576,63 @@ bool bvh8_build_device(const float* verts, const int32_t* obj, const int32_t* pr
         DCHK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys_in, d_keys, d_vals_in, d_vals, (size_t)n, 0u, 63u, st));
     }
 
-    // 3./4. radix tree and its boxes
+    // 3. binary tree over the sorted order, with the boxes of its inner nodes
     uint32_t root_ref = LEAF | 0u;
-    if (n >= 2) {
+    const char* kind = getenv("WAPT_DEVICE_BVH");
+    const bool lbvh = kind && !strcmp(kind, "lbvh");
+    if (n >= 2 && lbvh) {
         hipLaunchKernelGGL(k_hierarchy, dim3((n - 1 + 255) / 256), dim3(256), 0, st, d_keys, n, d_left, d_right, d_first, d_count,
                            d_pin, d_pleaf);
         hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, st, d_tbox, d_vals, n, d_left, d_right, d_pin, d_pleaf, d_ibox, d_flags);
         root_ref = 0u;
+    } else if (n >= 2) {
+        int radius = 8;
+        if (const char* e = getenv("WAPT_PLOC_RADIUS")) radius = std::min(64, std::max(1, atoi(e)));
+        Box6 *d_cb_a, *d_cb_b;
+        uint32_t *d_nn, *d_keep, *d_pos, *d_nodes_made;
+        if (!B.alloc(&d_cb_a, n, err) || !B.alloc(&d_cb_b, n, err) || !B.alloc(&d_nn, n, err) || !B.alloc(&d_keep, n, err) ||
+            !B.alloc(&d_pos, n, err) || !B.alloc(&d_nodes_made, 4, err))
+            return false;
+        size_t scan_bytes = 0;
+        DCHK(rocprim::exclusive_scan(nullptr, scan_bytes, d_keep, d_pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+        char* d_scan_tmp;
+        if (!B.alloc(&d_scan_tmp, scan_bytes, err)) return false;
+        DCHK(hipMemsetAsync(d_nodes_made, 0, 16, st));
+        // the cluster lists alternate between (refs_a, cb_a) and (refs_b, cb_b)
+        uint32_t *C = d_refs_a, *C2 = d_refs_b;
+        Box6 *cb1 = d_cb_a, *cb2 = d_cb_b;
+        hipLaunchKernelGGL(k_ploc_init, dim3(nb), dim3(256), 0, st, d_tbox, d_vals, n, C, cb1);
+        uint32_t m = n;
+        int rounds = 0;
+        bool stalled = false;  // the last round merged next to nothing (never seen on real scenes: rounds remove 15-40 %)
+        while (m > 1) {
+            if (++rounds > 4096) {
+                *err = "clustering did not converge";
+                return false;
+            }
+            const dim3 g((m + 255) / 256);
+            hipLaunchKernelGGL(k_ploc_nearest, g, dim3(256), 0, st, cb1, m, stalled ? 0 : radius, d_nn);
+            hipLaunchKernelGGL(k_ploc_merge, g, dim3(256), 0, st, C, cb1, d_nn, m, d_left, d_right, d_count, d_ibox, d_nodes_made, C2, cb2,
+                               d_keep);
+            DCHK(rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_keep, d_pos, 0u, (size_t)m, rocprim::plus<uint32_t>(), st));
+            hipLaunchKernelGGL(k_ploc_compact, g, dim3(256), 0, st, C2, cb2, d_keep, d_pos, m, C, cb1);
+            uint32_t made = 0;
+            DCHK(hipMemcpyAsync(&made, d_nodes_made, 4, hipMemcpyDeviceToHost, st));
+            DCHK(hipStreamSynchronize(st));
+            const uint32_t m_new = n - made;  // every merge removes one cluster
+            if (m_new >= m) {
+                *err = "clustering made no progress";
+                return false;
+            }
+            stalled = (m - m_new) < m / 256u && m > 1024u;
+            if (getenv("WAPT_PLOC_VERBOSE")) fprintf(stderr, "ploc round %d: %u -> %u clusters%s\n", rounds, m, m_new, stalled ? " (stalled)" : "");
+            m = m_new;
+        }
+        DCHK(hipMemcpyAsync(&root_ref, C, 4, hipMemcpyDeviceToHost, st));
+        DCHK(hipStreamSynchronize(st));
     }
     Box6 root_box;
-    if (n >= 2) DCHK(hipMemcpyAsync(&root_box, d_ibox, sizeof(Box6), hipMemcpyDeviceToHost, st));
+    if (n >= 2) DCHK(hipMemcpyAsync(&root_box, d_ibox + (root_ref & ~LEAF), sizeof(Box6), hipMemcpyDeviceToHost, st));
     else DCHK(hipMemcpyAsync(&root_box, d_tbox, sizeof(Box6), hipMemcpyDeviceToHost, st));
     DCHK(hipStreamSynchronize(st));
     DCHK(hipGetLastError());

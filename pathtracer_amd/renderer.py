@@ -14,10 +14,10 @@ from .scene import Scene
 
 
 class wa_content:
-    """Scene resident on one GPU (BVH built by the library on the host at construction)."""
+    """Scene resident on one GPU (BVH built by the library at construction)."""
 
     def __init__(self, scene: Scene, device: int = 0, builder: str = "auto"):
-        """builder: "auto" (host SAH below 2^24 triangles, device LBVH above), "host" or "device"."""
+        """builder: "auto" (the device builder), "host" (binned SAH on the CPU) or "device"."""
         self.scene = scene
         self.device = device
         self._h = C.c_void_p()

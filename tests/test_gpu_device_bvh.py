@@ -69,3 +69,21 @@ def test_same_seed_image_through_the_device_tree():
     ref = oracle_api.OracleScene(sc).render(16, 1, 1, seed=4, threads=16)
     close = np.abs(fb - ref) <= 2e-3 * np.abs(ref) + 1e-4
     assert close.all(-1).mean() >= 0.995
+
+
+def test_thousands_of_coincident_triangles_do_not_stall_the_clustering():
+    """Every cluster of a run of identical boxes prefers the same partner, so a plain nearest-neighbour round merges
+    one pair; the builder must notice and pair by position instead.  Same hits as through the host-built tree."""
+    from pathtracer_amd.scene import Scene, material
+    base = scenes.cornell(res=(8, 8), spheres=False)
+    one = np.array([[[100, 100, 300], [200, 100, 300], [100, 200, 300]]], np.float32)
+    many = np.repeat(one, 30_000, axis=0)
+    sc = Scene(base.camera, base.lights, [material("diffuse", (0.5, 0.5, 0.5))] * 2,
+               [base.tri_verts[base.tri_obj >= len(base.lights)].reshape(-1, 3, 3), many], td=1)
+    rays = helpers.random_rays(sc, 20_000, seed=5)
+    hd, info = _hits(sc, rays, "device")
+    hh, _ = _hits(sc, rays, "host")
+    assert info.n_tris == len(sc.tri_obj)
+    # the duplicates tie with each other: compare distances and objects, not primitive numbers
+    assert (hd["obj"] == hh["obj"]).mean() >= 0.9999
+    np.testing.assert_allclose(hd["t"], hh["t"], rtol=1e-5)
