@@ -18,7 +18,7 @@ Work per step
 
 Rank 0 prints one JSON line.  `value` is whole-job Mpaths/s (a path = one pixel sample = one top-level radiance()
 call).  `roofline` prices the dominant kernel, the closest-hit traversal k_trace:
-  * the bound that holds it is VALU issue, not HBM (the 60 MB tree is served by L2 and Infinity Cache), so
+  * the bound that holds it is VALU issue, not HBM (the 52 MB tree is served by L2 and Infinity Cache), so
     `achieved` is wave64 VALU instructions per second = (SQ_INSTS_VALU of the kernel / its rays) x rays per second in
     the kernel (HIP events on the library's stream), against `peak` = 1024 SIMDs x 2.4 GHz / 2 cycles per instruction;
   * the algorithmic byte rate (32 B ray + 8 B hit + 80 B x node visits + 48 B x triangle tests per ray, the visit counts
@@ -350,7 +350,7 @@ def main():
                 "bytes_per_ray": bytes_per_ray, "node_visits_per_ray": nodes_per_ray, "tri_tests_per_ray": tris_per_ray,
                 "algorithmic_gbs": algorithmic_gbs, "algorithmic_frac_of_l2_peak": algorithmic_gbs / L2_PEAK_GBS,
                 "algorithmic_frac_of_hbm_peak": algorithmic_gbs / HBM_PEAK_GBS,
-                "note": "algorithmic bytes are served by L2 / Infinity Cache (60 MB tree), hence a rate above the HBM peak; "
+                "note": "algorithmic bytes are served by L2 / Infinity Cache (52 MB tree), hence a rate above the HBM peak; "
                         "the kernel is priced against VALU issue",
                 "kernel_ms_per_step": fam_ms, "lane_utilisation": util,
                 "shadow_rays_per_step": int(shadow_rays), "probe_rays_per_step": int(st.n_probe_rays)}
