@@ -18,9 +18,16 @@ Work per step
 
 Rank 0 prints one JSON line.  `value` is whole-job Mpaths/s (a path = one pixel sample = one top-level radiance()
 call).  `roofline` prices the dominant kernel, the closest-hit traversal k_trace:
-  * the bound that holds it is VALU issue, not HBM (the 52 MB tree is served by L2 and Infinity Cache), so
-    `achieved` is wave64 VALU instructions per second = (SQ_INSTS_VALU of the kernel / its rays) x rays per second in
-    the kernel (HIP events on the library's stream), against `peak` = 1024 SIMDs x 2.4 GHz / 2 cycles per instruction;
+  * the bound that holds it is VALU issue, not HBM (the 52 MB tree is served by L2 and Infinity Cache).  A wave64
+    vector instruction occupies its SIMD for 2 cycles if it is an f32 add / mul / fma, a two-operand logic operation,
+    an integer add or a move, for 4 if it is anything else (min / max, compares, selects, conversions, shifts ...) and
+    for 8 if it is a transcendental (measured: tools/probes/valu_rate.hip, profiles/r02_valu_issue_cost.txt).  So
+    `achieved` is VALU issue cycles per second = (issue cycles per ray) x rays per second in the kernel (HIP events on
+    the library's stream), against `peak` = 1024 SIMDs x 2.4 GHz; issue cycles per ray = the kernel's instruction
+    counters by class (SQ_INSTS_VALU_FMA_F32, _MUL_F32, _ADD_F32, _CVT, _TRANS_F32), each at its cost, plus the
+    instructions no class counter breaks out at the mean cost of such instructions in the kernel's ISA
+    (profiles/valu_issue_mix.json, `make -C pathtracer_amd/csrc isa`).  `insts_frac_at_2_cycles` is the same
+    instruction count priced as if every instruction took 2 cycles (a lower bound of the utilisation);
   * the algorithmic byte rate (32 B ray + 8 B hit + 80 B x node visits + 48 B x triangle tests per ray, the visit counts
     measured by the counting build of the same kernel on the same rays) is given against L2 and against HBM;
   * `traffic` is the kernel's memory-side bytes per launch from the FETCH_SIZE / WRITE_SIZE counters.
@@ -47,10 +54,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth of the 8 XCDs
 SIMDS = 256 * 4
-VALU_PEAK_GINST = SIMDS * 2.4e9 / 2.0 / 1e9   # wave64 VALU instructions per second: one per 2 cycles per SIMD at 2.4 GHz
+CLOCK_GHZ = 2.4
+VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / 2.0     # G wave64 VALU instructions per second if every one took 2 cycles
+VALU_PEAK_GCYCLES = SIMDS * CLOCK_GHZ         # G VALU issue cycles per second (all SIMDs)
+ISSUE_COST = {"SQ_INSTS_VALU_FMA_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_INSTS_VALU_ADD_F32": 2.0,
+              "SQ_INSTS_VALU_CVT": 4.0, "SQ_INSTS_VALU_TRANS_F32": 8.0}
 
 PMC_PASSES = [
     ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE"]),
+    ("mix", ["SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_CVT",
+             "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_SALU"]),
     ("fetch", ["FETCH_SIZE", "TCC_HIT_sum"]),       # FETCH_SIZE takes 3 of the 4 TCC slots
     ("write", ["WRITE_SIZE", "TCC_MISS_sum"]),      # WRITE_SIZE takes 2
 ]
@@ -62,7 +75,7 @@ def family(kernel_name):
 
 
 def collect_pmc(child_args, log):
-    """Runs the three counter passes over a child of this script; returns {family: {counter: sum, "launches": n}}."""
+    """Runs the counter passes over a child of this script; returns {family: {counter: sum, "launches": n}}."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         raise RuntimeError("rocprofv3 not found")
@@ -95,6 +108,36 @@ def collect_pmc(child_args, log):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
+
+
+def static_mix(fam):
+    """Mean issue cost of the instructions of a kernel family that no class counter breaks out, and of all its
+    instructions, from the ISA of the shipped kernels (non-counting instances); (4.0, 4.0) if the file is missing."""
+    try:
+        ks = json.load(open(os.path.join(ROOT, "profiles", "valu_issue_mix.json")))["kernels"]
+        sel = [v for k, v in ks.items() if k.split("<")[0] == fam and (("<" not in k) or k.split("<")[1].startswith("false"))]
+        if sel:
+            return (sum(v["rest_mean_cost"] for v in sel) / len(sel), sum(v["mean_cost"] for v in sel) / len(sel))
+    except Exception:  # noqa: BLE001
+        pass
+    return (4.0, 4.0)
+
+
+def issue_cycles(c, fam):
+    """VALU issue cycles of a kernel family's launches from its counters (see the module docstring); None without them."""
+    n = c.get("SQ_INSTS_VALU")
+    if not n:
+        return None, None
+    rest_cost, mean_cost = static_mix(fam)
+    if all(k in c for k in ISSUE_COST):
+        counted = sum(c[k] for k in ISSUE_COST)
+        cycles = sum(c[k] * w for k, w in ISSUE_COST.items()) + max(n - counted, 0.0) * rest_cost
+        how = {"classes_per_inst": {k.replace("SQ_INSTS_VALU_", "").lower(): c[k] / n for k in ISSUE_COST},
+               "rest_per_inst": max(n - counted, 0.0) / n, "rest_mean_cost": rest_cost}
+    else:
+        cycles = n * mean_cost
+        how = {"mean_cost_static": mean_cost}
+    return cycles, how
 
 
 def git_sha():
@@ -342,8 +385,9 @@ def main():
                     log.append(f"committed counter summary unreadable: {e}")
 
         roof = {"bound": "valu", "kernel": "k_trace (closest hit, one ray per lane)",
-                "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s", "frac": None,
-                "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction",
+                "achieved": None, "peak": VALU_PEAK_GCYCLES, "unit": "G VALU issue cycles/s", "frac": None,
+                "peak_definition": "1024 SIMDs x 2.4 GHz; a wave64 instruction takes 2, 4 or 8 issue cycles by kind "
+                                   "(tools/probes/valu_rate.hip, profiles/r02_valu_issue_cost.txt)",
                 "traffic": None, "counter_source": pmc_source,
                 "rays_per_launch": rays_per_launch, "avg_launch_ms": avg_ms, "launches_per_step": int(n_launch),
                 "grays_per_s_in_kernel": grays_kernel,
@@ -358,9 +402,17 @@ def main():
             kt = pmc.get("k_trace", {})
             if kt.get("SQ_INSTS_VALU") and n_rays:
                 ipr = kt["SQ_INSTS_VALU"] / float(n_rays)   # wave-instructions of the frame's launches / its rays
+                cyc, how = issue_cycles(kt, "k_trace")
                 roof["valu_insts_per_ray"] = ipr
-                roof["achieved"] = ipr * grays_kernel
-                roof["frac"] = roof["achieved"] / VALU_PEAK_GINST
+                roof["valu_issue_cycles_per_ray"] = cyc / float(n_rays)
+                roof["valu_issue_mix"] = how
+                roof["achieved"] = roof["valu_issue_cycles_per_ray"] * grays_kernel
+                roof["frac"] = roof["achieved"] / VALU_PEAK_GCYCLES
+                roof["insts_frac_at_2_cycles"] = ipr * grays_kernel / VALU_PEAK_GINST
+                if kt.get("GRBM_GUI_ACTIVE") and ms_trace:
+                    # the counter sums the 8 XCDs; over the kernel's time it gives the clock the launch really ran at
+                    roof["clock_ghz_measured"] = kt["GRBM_GUI_ACTIVE"] / 8.0 / (ms_trace * 1e-3) / 1e9
+                    roof["frac_at_measured_clock"] = roof["achieved"] / (SIMDS * roof["clock_ghz_measured"])
             if "FETCH_SIZE" in kt and "WRITE_SIZE" in kt:
                 nl = max(kt.get("launches", n_launch), 1)
                 f_raw, w = kt["FETCH_SIZE"] * 1024.0 / nl, kt["WRITE_SIZE"] * 1024.0 / nl   # the counters are in KiB
@@ -381,6 +433,10 @@ def main():
                 f_raw, w = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
                 per_kernel[fam] = {"fetch_raw_gb": f_raw / 1e9, "write_gb": w / 1e9, "launches": c.get("launches"),
                                    "valu_insts": c.get("SQ_INSTS_VALU")}
+                fam_key = {"k_trace": "trace", "k_surface": "shade", "k_shadow": "shadow", "k_probe": "probe", "k_volume": "volume"}.get(fam)
+                cyc_f, _ = issue_cycles(c, fam)
+                if fam_key and cyc_f and fam_ms.get(fam_key):
+                    per_kernel[fam]["valu_issue_frac"] = cyc_f / (fam_ms[fam_key] * 1e-3) / 1e9 / VALU_PEAK_GCYCLES
                 raw_sum += f_raw + w
                 x2_sum += 2.0 * f_raw + w
             step_s = out["ms_per_step"] * 1e-3
