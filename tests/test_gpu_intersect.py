@@ -109,3 +109,34 @@ def test_unusual_rays_end_as_misses_or_agree_with_the_checker(content_mod):
     want = oracle_api.OracleScene(sc).intersect(fine, threads=2)
     assert (h["prim"] == want["prim"]).all() and (h["obj"] == want["obj"]).all()
     np.testing.assert_allclose(h["t"], want["t"], rtol=1e-5)
+
+
+def test_axis_parallel_rays_with_signed_zero_components(content_mod):
+    # rays along one axis, the other two components +0.0 or -0.0 in every combination, from inside the box: a
+    # component of -0.0 has a negative reciprocal, so the near and far planes of its slab swap like for any negative one
+    sc = scenes.cornell(res=(64, 64), spheres=True)
+    o = oracle_api.OracleScene(sc)
+    v = sc.tri_verts.reshape(-1, 3)
+    lo, hi = v.min(0).astype(np.float32), v.max(0).astype(np.float32)
+    rng = np.random.default_rng(11)
+    rows = []
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            for za in (0.0, -0.0):
+                for zb in (0.0, -0.0):
+                    d = [za, zb]
+                    d.insert(axis, sign)
+                    for _ in range(50):
+                        p = lo + (hi - lo) * rng.uniform(0.2, 0.8, 3).astype(np.float32)
+                        rows.append([p[0], p[1], p[2], 0.001, d[0], d[1], d[2], 1e7])
+    rays = np.array(rows, np.float32)
+    assert np.signbit(rays[:, 4:7]).any(axis=1).sum() > len(rays) // 2
+    c = content_mod.wa_content(sc)
+    try:
+        got = c.traceFAST(rays)
+    finally:
+        c.close()
+    want = o.intersect(rays, brute=True, threads=8)
+    frac, worst, bad, ties = helpers.compare_hits(got, want)
+    assert (want["prim"] >= 0).mean() > 0.8  # (the box is closed on five sides)
+    assert bad == 0 and worst <= 1e-5

@@ -1,8 +1,8 @@
 """VALU issue cycles per basic block of the kernels in a -save-temps ISA file, priced with the issue costs that
 tools/probes/valu_rate.hip measures on gfx950 with a full SIMD (profiles/r02_valu_issue_cost.txt): 2 cycles for f32
-add / sub / mul / fma / fmac, and / or / xor / not, add / sub u32, mov, lshrrev and bitop3; 8 for transcendentals and
-64-bit operations; 4 for everything else (min / max, compares, cndmask, conversions, shifts left, bfe / bfi / perm,
-three-operand integer forms, DPP and SDWA forms, all packed 16-bit forms).
+add / sub / mul / fma / fmac, and / or / xor / not, add / sub u32, mov, lshrrev, ashrrev and bitop3; 8 for
+transcendentals; 4 for everything else (min / max, compares, cndmask, conversions, shifts left, bfe / bfi / perm,
+three-operand integer forms, DPP and SDWA forms, packed f32 and 16-bit forms, f64 add / mul / fma).
   python tools/isa_cost.py <file.s> <kernel symbol>          per-block table of one kernel
   python tools/isa_cost.py <file.s> --json <out.json>        per-kernel totals of all k_* kernels: instructions by
                                                              class and the mean issue cost of the instructions that
@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 FAST = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_and_b32", "v_or_b32", "v_xor_b32",
-        "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mov_b32", "v_lshrrev_b32", "v_bitop3_b32", "v_add_co_u32",
+        "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mov_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_bitop3_b32", "v_add_co_u32",
         "v_addc_co_u32", "v_accvgpr_read_b32", "v_accvgpr_write_b32"}
 TRANS = {"v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32"}
 # what the SQ_INSTS_VALU_{FMA,MUL,ADD}_F32, _CVT and _TRANS_F32 counters break out
@@ -32,8 +32,8 @@ def cost(op):
         return 2
     if base in TRANS:
         return 8
-    if base.endswith("_f64") or "_u64" in base or "_b64" in base or "_i64" in base:
-        return 8
+    if base in ("v_mad_u64_u32", "v_mad_i64_i32", "v_div_scale_f64", "v_div_fmas_f64", "v_div_fixup_f64", "v_rcp_f64", "v_sqrt_f64"):
+        return 8  # (not measured)
     return 4
 
 

@@ -169,6 +169,153 @@ KERNEL(k_68, OP_68)
 #define OP_69(i) "v_mad_i32_i24 %" #i ", %" #i ", %8, %9\n"
 KERNEL(k_69, OP_69)
 
+#define OP_ASHR(i) "v_ashrrev_i32 %" #i ", 31, %" #i "\n"
+KERNEL(k_ashr, OP_ASHR)
+#define OP_BFM(i) "v_bfm_b32 %" #i ", %" #i ", %8\n"
+KERNEL(k_bfm, OP_BFM)
+#define OP_SUBREV(i) "v_subrev_u32 %" #i ", 1, %" #i "\n"
+KERNEL(k_subrev, OP_SUBREV)
+
+// packed f32 forms work on register pairs
+#define BODY8W(OP)                                                                        \
+    asm volatile(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)                          \
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) \
+                 : "v"(xx), "v"(yy));
+#define KERNELW(NAME, OP)                                                                 \
+    __global__ __launch_bounds__(256) void NAME(unsigned long long* out, uint32_t* sink, uint32_t x, uint32_t y) { \
+        unsigned long long b[8], xx = x | ((unsigned long long)y << 32), yy = y | ((unsigned long long)x << 32); \
+        for (int i = 0; i < 8; i++) b[i] = threadIdx.x + i;                               \
+        unsigned long long t0 = __builtin_readcyclecounter();                             \
+        for (int it = 0; it < ITER; it++) {                                               \
+            BODY8W(OP) BODY8W(OP) BODY8W(OP) BODY8W(OP) BODY8W(OP) BODY8W(OP) BODY8W(OP) BODY8W(OP) \
+        }                                                                                 \
+        unsigned long long t1 = __builtin_readcyclecounter();                             \
+        unsigned long long s = 0;                                                         \
+        for (int i = 0; i < 8; i++) s ^= b[i];                                            \
+        if (s == 0x12345678ull) sink[0] = (uint32_t)s;                                    \
+        if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0; \
+    }
+#define OP_PKFMA32(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_PKFMA32B(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9 op_sel_hi:[1,0,0]\n"
+#define OP_PKMUL32(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n"
+#define OP_PKADD32(i) "v_pk_add_f32 %" #i ", %" #i ", %8\n"
+#define OP_PKMOV(i) "v_pk_mov_b32 %" #i ", %" #i ", %8\n"
+#define OP_FMA64(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\n"
+#define OP_ADD64(i) "v_add_f64 %" #i ", %" #i ", %8\n"
+#define OP_MUL64(i) "v_mul_f64 %" #i ", %" #i ", %8\n"
+#define OP_LSHLADD64(i) "v_lshl_add_u64 %" #i ", %" #i ", 3, %8\n"
+KERNELW(k_pkfma32, OP_PKFMA32)
+KERNELW(k_pkfma32b, OP_PKFMA32B)
+KERNELW(k_pkmul32, OP_PKMUL32)
+KERNELW(k_pkadd32, OP_PKADD32)
+KERNELW(k_pkmov, OP_PKMOV)
+KERNELW(k_fma64, OP_FMA64)
+KERNELW(k_add64, OP_ADD64)
+KERNELW(k_mul64, OP_MUL64)
+KERNELW(k_lshladd64, OP_LSHLADD64)
+
+// mixes of a 2-cycle and a 4-cycle kind: do the two kinds share one issue port (6 cycles per pair) or not (4)?
+#define OP_MIX1(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\nv_min_f32 %" #i ", %" #i ", %8\n"
+#define OP_MIX2(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\nv_fma_f32 %" #i ", %" #i ", %9, %8\nv_min_f32 %" #i ", %" #i ", %8\n"
+#define OP_MIX3(i) "v_cvt_f32_ubyte1 %" #i ", %" #i "\nv_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_MIX4(i) "v_and_b32 %" #i ", %" #i ", %8\nv_lshlrev_b32 %" #i ", 1, %" #i "\n"
+KERNEL(k_mix1, OP_MIX1)
+KERNEL(k_mix2, OP_MIX2)
+KERNEL(k_mix3, OP_MIX3)
+KERNEL(k_mix4, OP_MIX4)
+
+#define OPX_0(i) "v_fma_f32 %0, %0, %8, %9\nv_min_f32 %4, %4, %8\nv_fma_f32 %1, %1, %8, %9\nv_min_f32 %5, %5, %8\nv_fma_f32 %2, %2, %8, %9\nv_min_f32 %6, %6, %8\nv_fma_f32 %3, %3, %8, %9\nv_min_f32 %7, %7, %8\nv_fma_f32 %4, %4, %8, %9\nv_min_f32 %0, %0, %8\nv_fma_f32 %5, %5, %8, %9\nv_min_f32 %1, %1, %8\nv_fma_f32 %6, %6, %8, %9\nv_min_f32 %2, %2, %8\nv_fma_f32 %7, %7, %8, %9\nv_min_f32 %3, %3, %8\n"
+#define BODYX_0 asm volatile(OPX_0(0) : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(y) : "vcc");
+__global__ __launch_bounds__(256) void kx_0(unsigned long long* out, uint32_t* sink, uint32_t x, uint32_t y) {
+    uint32_t a[8];
+    for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) { BODYX_0 BODYX_0 BODYX_0 BODYX_0 BODYX_0 BODYX_0 BODYX_0 BODYX_0 }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s ^= a[i];
+    if (s == 0x12345678u) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+#define OPX_1(i) "v_and_b32 %0, %0, %8\nv_min_f32 %4, %4, %8\nv_and_b32 %1, %1, %8\nv_min_f32 %5, %5, %8\nv_and_b32 %2, %2, %8\nv_min_f32 %6, %6, %8\nv_and_b32 %3, %3, %8\nv_min_f32 %7, %7, %8\nv_and_b32 %4, %4, %8\nv_min_f32 %0, %0, %8\nv_and_b32 %5, %5, %8\nv_min_f32 %1, %1, %8\nv_and_b32 %6, %6, %8\nv_min_f32 %2, %2, %8\nv_and_b32 %7, %7, %8\nv_min_f32 %3, %3, %8\n"
+#define BODYX_1 asm volatile(OPX_1(0) : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(y) : "vcc");
+__global__ __launch_bounds__(256) void kx_1(unsigned long long* out, uint32_t* sink, uint32_t x, uint32_t y) {
+    uint32_t a[8];
+    for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) { BODYX_1 BODYX_1 BODYX_1 BODYX_1 BODYX_1 BODYX_1 BODYX_1 BODYX_1 }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s ^= a[i];
+    if (s == 0x12345678u) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+#define OPX_2(i) "v_bitop3_b32 %0, %0, %8, %9 bitop3:0x96\nv_cvt_f32_ubyte1 %4, %4\nv_bitop3_b32 %1, %1, %8, %9 bitop3:0x96\nv_cvt_f32_ubyte1 %5, %5\nv_bitop3_b32 %2, %2, %8, %9 bitop3:0x96\nv_cvt_f32_ubyte1 %6, %6\nv_bitop3_b32 %3, %3, %8, %9 bitop3:0x96\nv_cvt_f32_ubyte1 %7, %7\nv_bitop3_b32 %4, %4, %8, %9 bitop3:0x96\nv_cvt_f32_ubyte1 %0, %0\nv_bitop3_b32 %5, %5, %8, %9 bitop3:0x96\nv_cvt_f32_ubyte1 %1, %1\nv_bitop3_b32 %6, %6, %8, %9 bitop3:0x96\nv_cvt_f32_ubyte1 %2, %2\nv_bitop3_b32 %7, %7, %8, %9 bitop3:0x96\nv_cvt_f32_ubyte1 %3, %3\n"
+#define BODYX_2 asm volatile(OPX_2(0) : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(y) : "vcc");
+__global__ __launch_bounds__(256) void kx_2(unsigned long long* out, uint32_t* sink, uint32_t x, uint32_t y) {
+    uint32_t a[8];
+    for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) { BODYX_2 BODYX_2 BODYX_2 BODYX_2 BODYX_2 BODYX_2 BODYX_2 BODYX_2 }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s ^= a[i];
+    if (s == 0x12345678u) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+#define OPX_3(i) "v_mov_b32 %0, %8\nv_lshlrev_b32 %4, 1, %4\nv_mov_b32 %1, %8\nv_lshlrev_b32 %5, 1, %5\nv_mov_b32 %2, %8\nv_lshlrev_b32 %6, 1, %6\nv_mov_b32 %3, %8\nv_lshlrev_b32 %7, 1, %7\nv_mov_b32 %4, %8\nv_lshlrev_b32 %0, 1, %0\nv_mov_b32 %5, %8\nv_lshlrev_b32 %1, 1, %1\nv_mov_b32 %6, %8\nv_lshlrev_b32 %2, 1, %2\nv_mov_b32 %7, %8\nv_lshlrev_b32 %3, 1, %3\n"
+#define BODYX_3 asm volatile(OPX_3(0) : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(y) : "vcc");
+__global__ __launch_bounds__(256) void kx_3(unsigned long long* out, uint32_t* sink, uint32_t x, uint32_t y) {
+    uint32_t a[8];
+    for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) { BODYX_3 BODYX_3 BODYX_3 BODYX_3 BODYX_3 BODYX_3 BODYX_3 BODYX_3 }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s ^= a[i];
+    if (s == 0x12345678u) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+#define OPX_4(i) "v_fma_f32 %0, %0, %8, %9\nv_fma_f32 %4, %4, %9, %8\nv_fma_f32 %1, %1, %8, %9\nv_fma_f32 %5, %5, %9, %8\nv_fma_f32 %2, %2, %8, %9\nv_fma_f32 %6, %6, %9, %8\nv_fma_f32 %3, %3, %8, %9\nv_fma_f32 %7, %7, %9, %8\nv_fma_f32 %4, %4, %8, %9\nv_fma_f32 %0, %0, %9, %8\nv_fma_f32 %5, %5, %8, %9\nv_fma_f32 %1, %1, %9, %8\nv_fma_f32 %6, %6, %8, %9\nv_fma_f32 %2, %2, %9, %8\nv_fma_f32 %7, %7, %8, %9\nv_fma_f32 %3, %3, %9, %8\n"
+#define BODYX_4 asm volatile(OPX_4(0) : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(y) : "vcc");
+__global__ __launch_bounds__(256) void kx_4(unsigned long long* out, uint32_t* sink, uint32_t x, uint32_t y) {
+    uint32_t a[8];
+    for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) { BODYX_4 BODYX_4 BODYX_4 BODYX_4 BODYX_4 BODYX_4 BODYX_4 BODYX_4 }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s ^= a[i];
+    if (s == 0x12345678u) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+#define OPX_5(i) "v_min_f32 %0, %0, %8\nv_cvt_f32_ubyte1 %4, %4\nv_min_f32 %1, %1, %8\nv_cvt_f32_ubyte1 %5, %5\nv_min_f32 %2, %2, %8\nv_cvt_f32_ubyte1 %6, %6\nv_min_f32 %3, %3, %8\nv_cvt_f32_ubyte1 %7, %7\nv_min_f32 %4, %4, %8\nv_cvt_f32_ubyte1 %0, %0\nv_min_f32 %5, %5, %8\nv_cvt_f32_ubyte1 %1, %1\nv_min_f32 %6, %6, %8\nv_cvt_f32_ubyte1 %2, %2\nv_min_f32 %7, %7, %8\nv_cvt_f32_ubyte1 %3, %3\n"
+#define BODYX_5 asm volatile(OPX_5(0) : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(y) : "vcc");
+__global__ __launch_bounds__(256) void kx_5(unsigned long long* out, uint32_t* sink, uint32_t x, uint32_t y) {
+    uint32_t a[8];
+    for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) { BODYX_5 BODYX_5 BODYX_5 BODYX_5 BODYX_5 BODYX_5 BODYX_5 BODYX_5 }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s ^= a[i];
+    if (s == 0x12345678u) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+#define OPX_6(i) "v_add_u32 %0, %0, %8\nv_cmp_lt_f32 vcc, %4, %8\nv_add_u32 %1, %1, %8\nv_cmp_lt_f32 vcc, %5, %8\nv_add_u32 %2, %2, %8\nv_cmp_lt_f32 vcc, %6, %8\nv_add_u32 %3, %3, %8\nv_cmp_lt_f32 vcc, %7, %8\nv_add_u32 %4, %4, %8\nv_cmp_lt_f32 vcc, %0, %8\nv_add_u32 %5, %5, %8\nv_cmp_lt_f32 vcc, %1, %8\nv_add_u32 %6, %6, %8\nv_cmp_lt_f32 vcc, %2, %8\nv_add_u32 %7, %7, %8\nv_cmp_lt_f32 vcc, %3, %8\n"
+#define BODYX_6 asm volatile(OPX_6(0) : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(x), "v"(y) : "vcc");
+__global__ __launch_bounds__(256) void kx_6(unsigned long long* out, uint32_t* sink, uint32_t x, uint32_t y) {
+    uint32_t a[8];
+    for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) { BODYX_6 BODYX_6 BODYX_6 BODYX_6 BODYX_6 BODYX_6 BODYX_6 BODYX_6 }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+    for (int i = 0; i < 8; i++) s ^= a[i];
+    if (s == 0x12345678u) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
 typedef void (*kern_t)(unsigned long long*, uint32_t*, uint32_t, uint32_t);
 
 int main() {
@@ -247,7 +394,11 @@ int main() {
         {"v_cmp_class_f32", k_66},
         {"v_fract_f32", k_67},
         {"v_ldexp_f32", k_68},
-        {"v_mad_i32_i24", k_69}};
+        {"v_mad_i32_i24", k_69},
+        {"v_ashrrev_i32", k_ashr}, {"v_bfm_b32", k_bfm}, {"v_subrev_u32", k_subrev},
+        {"v_pk_fma_f32", k_pkfma32}, {"v_pk_fma_f32 op_sel", k_pkfma32b}, {"v_pk_mul_f32", k_pkmul32}, {"v_pk_add_f32", k_pkadd32},
+        {"v_pk_mov_b32", k_pkmov}, {"v_fma_f64", k_fma64}, {"v_add_f64", k_add64}, {"v_mul_f64", k_mul64}, {"v_lshl_add_u64", k_lshladd64},
+        {"fma+min (per pair)", k_mix1}, {"fma+fma+min (per triple)", k_mix2}, {"cvt_ubyte+fma (per pair)", k_mix3}, {"and+lshl (per pair)", k_mix4}, {"indep: fma+min (per pair)", kx_0}, {"indep: and+min (per pair)", kx_1}, {"indep: bitop3+cvt (per pair)", kx_2}, {"indep: mov+lshl (per pair)", kx_3}, {"indep: fma+fma (per pair)", kx_4}, {"indep: min+cvt (per pair)", kx_5}, {"indep: add_u32+cmp (per pair)", kx_6}};
     for (int wps : {8, 1}) {  // waves per SIMD
         const int blocks = cus * wps;  // 256 threads = 4 waves = one per SIMD
         const int waves = blocks * 4;
