@@ -1631,6 +1631,31 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     }
     if (s->n_nodes > WAPT_MAX_NODES || s->n_tris > WAPT_MAX_TRIS)
         return bail(wapt_fail(WAPT_E_LIMIT, "BVH larger than the traversal's 32-bit record addressing allows"));
+    if (getenv("WAPT_BVH_DUMP")) {
+        // the first levels of the tree as text (debugging aid): per node its children's kind and box
+        const uint32_t n_dump = (uint32_t)std::min<uint64_t>(s->n_nodes, env_u32("WAPT_BVH_DUMP", 9));
+        std::vector<Bvh8Node> top(n_dump);
+        HIPCHK_S(hipMemcpy(top.data(), s->d_nodes, n_dump * sizeof(Bvh8Node), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_dump; i++) {
+            const Bvh8Node& n = top[i];
+            fprintf(stderr, "node %u: child_base %u tri_base %u\n", i, n.child_base, n.tri_base);
+            const uint8_t* ql[3] = {n.qlo_x, n.qlo_y, n.qlo_z};
+            const uint8_t* qh[3] = {n.qhi_x, n.qhi_y, n.qhi_z};
+            for (int c = 0; c < 8; c++) {
+                if (!n.meta[c]) continue;
+                const bool inner = (n.meta[c] >> 5) == 1 && (n.meta[c] & 31) >= 24;
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; a++) {
+                    const float cell = std::ldexp(1.0f, (int)n.e[a] - 127);
+                    lo[a] = n.p[a] + ql[a][c] * cell;
+                    hi[a] = n.p[a] + qh[a][c] * cell;
+                }
+                const int cnt = inner ? 0 : ((n.meta[c] >> 5) == 7 ? 3 : (n.meta[c] >> 5) == 3 ? 2 : 1);
+                fprintf(stderr, "   slot %d %s%d  [%.3f %.3f %.3f] - [%.3f %.3f %.3f]\n", c, inner ? "inner " : "leaf x", cnt, lo[0], lo[1], lo[2],
+                        hi[0], hi[1], hi[2]);
+            }
+        }
+    }
     s->builder = builder;
     s->build_seconds = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
 
