@@ -21,7 +21,7 @@ call).  `roofline` prices the dominant kernel, the closest-hit traversal k_trace
   * the bound that holds it is VALU issue, not HBM (the 52 MB tree is served by L2 and Infinity Cache).  A wave64
     vector instruction occupies its SIMD for 2 cycles if it is an f32 add / mul / fma, a two-operand logic operation,
     an integer add or a move, for 4 if it is anything else (min / max, compares, selects, conversions, shifts ...) and
-    for 8 if it is a transcendental (measured: tools/probes/valu_rate.hip, profiles/r02_valu_issue_cost.txt).  So
+    for 8 if it is a transcendental (measured: tools/probes/valu_rate.hip, profiles/valu_issue_cost.txt).  So
     `achieved` is VALU issue cycles per second = (issue cycles per ray) x rays per second in the kernel (HIP events on
     the library's stream), against `peak` = 1024 SIMDs x 2.4 GHz; issue cycles per ray = the kernel's instruction
     counters by class (SQ_INSTS_VALU_FMA_F32, _MUL_F32, _ADD_F32, _CVT, _TRANS_F32), each at its cost, plus the
@@ -387,7 +387,7 @@ def main():
         roof = {"bound": "valu", "kernel": "k_trace (closest hit, one ray per lane)",
                 "achieved": None, "peak": VALU_PEAK_GCYCLES, "unit": "G VALU issue cycles/s", "frac": None,
                 "peak_definition": "1024 SIMDs x 2.4 GHz; a wave64 instruction takes 2, 4 or 8 issue cycles by kind "
-                                   "(tools/probes/valu_rate.hip, profiles/r02_valu_issue_cost.txt)",
+                                   "(tools/probes/valu_rate.hip, profiles/valu_issue_cost.txt)",
                 "traffic": None, "counter_source": pmc_source,
                 "rays_per_launch": rays_per_launch, "avg_launch_ms": avg_ms, "launches_per_step": int(n_launch),
                 "grays_per_s_in_kernel": grays_kernel,

@@ -1,5 +1,5 @@
 """VALU issue cycles per basic block of the kernels in a -save-temps ISA file, priced with the issue costs that
-tools/probes/valu_rate.hip measures on gfx950 with a full SIMD (profiles/r02_valu_issue_cost.txt): 2 cycles for f32
+tools/probes/valu_rate.hip measures on gfx950 with a full SIMD (profiles/valu_issue_cost.txt): 2 cycles for f32
 add / sub / mul / fma / fmac, and / or / xor / not, add / sub u32, mov, lshrrev, ashrrev and bitop3; 8 for
 transcendentals; 4 for everything else (min / max, compares, cndmask, conversions, shifts left, bfe / bfi / perm,
 three-operand integer forms, DPP and SDWA forms, packed f32 and 16-bit forms, f64 add / mul / fma).
