@@ -77,10 +77,12 @@ struct KParams {
     uint32_t sample_count;      // samples of this call
     int32_t rl, rr, rb, rt;     // pixel rectangle [rl, rr) x [rb, rt) that is rendered (setRegion, cpp:962-972)
     int32_t write_hits;         // the scene has media: keep refined hits and the list of marched segments for k_volume
-    int32_t pixel_major;        // task order: all samples of a pixel next to each other (else sample by sample;
-                                // experiment: without pre-reduction the pixel sums then contend, see WAPT_PIXEL_MAJOR)
-    // camera tasks made inside the depth-0 kernels: slot x of the step's chunk is sample cam_s0 + x / slots_per_sample,
-    // image slot x % slots_per_sample; the two divisions by launch constants as multiply-and-shift (udiv_magic)
+    int32_t pixel_major;        // task order: all samples of a pixel next to each other (the lanes of a wave then work on
+                                // one pixel: their camera rays, hit triangles and materials coincide, and the pixel's sum
+                                // takes one atomic request per wave, see wave_add_rgb); else sample by sample
+    // camera tasks made inside the depth-0 kernels.  Sample by sample: slot x of the step's chunk is sample
+    // cam_s0 + x / slots_per_sample, image slot x % slots_per_sample.  Pixel by pixel: image slot cam_s0 + x / sample_count,
+    // sample x % sample_count.  The divisions by launch constants as multiply-and-shift (udiv_magic).
     uint32_t cam_s0;
     uint32_t div_slots_m, div_slots_k, div_tiles_m, div_tiles_k;
 };
