@@ -883,6 +883,22 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
     unsigned long long m = __ballot(pred);
     if (m == 0ull) return;
     uint32_t lane = lane_id();
+    // Tasks ordered pixel by pixel: most lanes of a wave hold samples of ONE pixel.  The lanes on the pixel of the
+    // first of them are summed across the wave (three sums, one request); what is left goes the general way.
+    {
+        const uint32_t px0 = (uint32_t)__shfl((int)pixel, __ffsll((long long)m) - 1);
+        const bool maj = pred && pixel == px0;
+        if (__popcll(__ballot(maj)) > 2) {
+            const float r = wave_sum_f(maj ? c.x : 0.f), g = wave_sum_f(maj ? c.y : 0.f), b = wave_sum_f(maj ? c.z : 0.f);
+            if (lane < 3u) {
+                const float v = lane == 0u ? r : lane == 1u ? g : b;
+                if (v != 0.f) unsafeAtomicAdd(sum + (size_t)px0 * 3 + lane, v);
+            }
+            pred = pred && !maj;
+            m = __ballot(pred);
+            if (m == 0ull) return;
+        }
+    }
     if (pred) {
         uint32_t at = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         WAPT_CHECK_IDX(at, 64u, "staging slot of a pixel add");
@@ -893,19 +909,6 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint32_t n = (uint32_t)__popcll(m), n3 = 3u * n;
     const float* sf = (const float*)stage;
-    // all of them on one pixel (tasks ordered pixel by pixel: the lanes of a wave hold samples of the same pixel):
-    // three wave-wide sums and one request
-    const uint32_t px0 = f2u(sf[3]);
-    if (n > 2u && __ballot(pred && pixel != px0) == 0ull) {
-        float r = wave_sum_f(pred ? c.x : 0.f), g = wave_sum_f(pred ? c.y : 0.f), b = wave_sum_f(pred ? c.z : 0.f);
-        if (lane < 3u) {
-            float v = lane == 0u ? r : lane == 1u ? g : b;
-            if (v != 0.f) unsafeAtomicAdd(sum + (size_t)px0 * 3 + lane, v);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        return;
-    }
     for (uint32_t idx = lane; idx < n3; idx += 64u) {
         uint32_t e = (idx * 43691u) >> 17;  // idx / 3 for idx < 192
         uint32_t ch = idx - 3u * e;
@@ -2134,10 +2137,9 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     // (WAPT_FUSE_CAMERA=0 keeps the ray generation pass, for comparison).
     const char* fuse_env = getenv("WAPT_FUSE_CAMERA");
     bool fuse_camera = kp.dense_raygen && !s->has_scatter && !(fuse_env && fuse_env[0] == '0') && s->capR < (1u << 31);
-    // Task order.  Pixel by pixel where the camera tasks are made on the spot and a pixel's samples fit the queue
-    // (dragonChrome 1080p 256 spp: closest-hit, surface and shadow kernels -3 % each against sample by sample);
-    // sample by sample otherwise.  WAPT_PIXEL_MAJOR=0 / 1 overrides.
-    kp.pixel_major = pm_env ? (pm_env[0] != '0') : (fuse_camera && kp.sample_count > 1u && s->capR >= kp.sample_count);
+    // Task order: pixel by pixel (dragonChrome 1080p 256 spp: closest-hit and surface kernel -3 %, shadow kernel -6 %
+    // against sample by sample; glass +2 %, fog and milk +1 %).  WAPT_PIXEL_MAJOR=0 / 1 overrides.
+    kp.pixel_major = pm_env ? (pm_env[0] != '0') : (kp.sample_count > 1u);
     if (fuse_camera && (kp.pixel_major ? s->capR < kp.sample_count : s->capR < kp.slots_per_sample)) fuse_camera = false;
     udiv_magic(kp.pixel_major ? kp.sample_count : kp.slots_per_sample, &kp.div_slots_m, &kp.div_slots_k);
     udiv_magic(kp.tilesX, &kp.div_tiles_m, &kp.div_tiles_k);
