@@ -237,7 +237,10 @@ def main():
     # WAPT_BENCH_REHEARSAL=1: the multi-rank control flow on a box with ONE GPU - every rank renders on cuda:0 and the
     # collectives go through host copies over gloo (the numbers mean nothing; the sequence of collectives is the same)
     rehearsal = world > 1 and os.environ.get("WAPT_BENCH_REHEARSAL", "0") == "1"
-    if world > 1:
+    # WAPT_BENCH_FORCE_DIST=1: also with one rank the frame goes through RCCL (communicator of one; launched by
+    # torch.distributed.run): the collectives of the N > 1 flow next to this library's own streams, on one GPU
+    collectives = world > 1 or os.environ.get("WAPT_BENCH_FORCE_DIST", "0") == "1"
+    if collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
@@ -249,7 +252,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if collectives else 0)
 
     def reduce_sum_to_rank0(x):
         if rehearsal:
@@ -287,7 +290,7 @@ def main():
         acc.zero_()
         torch.cuda.synchronize()
         st = r.render_accumulate(acc.data_ptr(), begin, count, profile=profile)
-        if world > 1 and profile == 0:  # (the profiled frames below run on rank 0 alone: no collective there)
+        if collectives and profile == 0:  # (the profiled frames below run on rank 0 alone: no collective there)
             reduce_sum_to_rank0(acc)
         if rank == 0:
             torch.mul(acc, 1.0 / total_spp, out=image)
@@ -301,7 +304,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if collectives:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -316,7 +319,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, float(rays)], dtype=torch.float64, device="cpu" if rehearsal else dev)
-    if world > 1:
+    if collectives:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -497,7 +500,7 @@ def main():
             out["log"] = log
         print(json.dumps(out), flush=True)
     content.close()
-    if world > 1:
+    if collectives:
         dist.barrier()
         dist.destroy_process_group()
 

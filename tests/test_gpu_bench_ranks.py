@@ -43,3 +43,18 @@ def test_two_ranks_share_one_image_in_the_strong_scaling_mode():
     assert "7 spp image sharded over 2 GPU(s)" in d["config"]["workload"]
     # paths of the whole job = W x H x 7 per step
     assert abs(d["value"] * d["ms_per_step"] * 1e3 - 256 * 144 * 7) <= 1e-6 * 256 * 144 * 7
+
+
+def test_one_rank_through_rccl():
+    """The collectives of the N > 1 flow over RCCL itself (backend "nccl"), with the one rank this box has a GPU for:
+    process-group set-up on the device, reduce, barriers and all-reduces next to this library's own HIP stream."""
+    env = dict(os.environ, WAPT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--res", "256x144", "--scene", "cornell", "--spp", "4", "--no-pmc", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=240)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
