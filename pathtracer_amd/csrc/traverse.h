@@ -577,7 +577,10 @@ __device__ __forceinline__ WaveFeed wave_feed(uint32_t n, uint32_t* counters) {
     f.counter = counters + f.shard * WAPT_FEED_STRIDE;  // one 256-byte line per counter: atomics on words of
                                                         // one line queue behind each other like atomics on one word
     f.next = f.end = 0;
-    f.gshift = n >= (1u << 27) ? 9u : n >= (1u << 25) ? 8u : n >= (1u << 23) ? 7u : 6u;
+#ifndef WAPT_FEED_BIG_SHIFT
+#define WAPT_FEED_BIG_SHIFT 9u
+#endif
+    f.gshift = n >= (1u << 27) ? WAPT_FEED_BIG_SHIFT : n >= (1u << 25) ? 8u : n >= (1u << 23) ? 7u : 6u;
     f.dry = n == 0;
     return f;
 }
