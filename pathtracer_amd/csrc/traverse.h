@@ -198,9 +198,11 @@ __device__ __forceinline__ void trav_begin(Trav& t, V3 o, V3 d, float tmin, floa
 #ifndef WAPT_COOP_PER_LANE
 #define WAPT_COOP_PER_LANE 4
 #endif
-// 1: the one-search shadow kernel (scenes of opaque objects) uses the cooperative phase in its any-hit form
+// 1: the one-search shadow kernel (scenes of opaque objects) uses the cooperative phase in its any-hit form.
+// With tasks ordered sample by sample it cost the shadow kernel 3 %; ordered pixel by pixel (the lanes' walks start
+// close together and meet the same leaves) it gains: Cornell box +3.5 %, fog's shadow kernel -7 %, dragonChrome's -2.6 %.
 #ifndef WAPT_SHADOW_COOP
-#define WAPT_SHADOW_COOP 0
+#define WAPT_SHADOW_COOP 1
 #endif
 
 struct CoopLds {
