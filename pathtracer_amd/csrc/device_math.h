@@ -106,6 +106,9 @@ struct DLight {
     // area lights: no other object's surface lies in front of the quad closer than a shadow search can resolve
     // (set at scene creation, see light_front_is_clear): a walk that ends on the quad may stop searching short of it
     int32_t front_clear;
+    // number of this light among those that a probe ray (directLightHit, cpp:670-687) can hit, -1 for a light without
+    // geometry: the probes of a march sample lie light by light in their queue
+    int32_t probe_slot;
 };
 
 struct DCamera {

@@ -12,11 +12,17 @@
 // 16-byte words so that a wave reads and writes whole 1 KiB lines.
 //
 //   R  A = org.xyz | pixel     B = dir.xyz | info     C = beta.rgb | key
-//   S  A = from.xyz | pixel    B = to.xyz  | -        C = weight.rgb | -
-//   P  A = org.xyz | pixel     B = dir.xyz | info     C = weight.rgb | medium
+//   S  A = from.xyz | pixel    B = dir.xyz | target   C = weight.rgb | length
+//   P  (origin in VO)          B = dir.xyz | info     C = weight.rgb | medium
 //
-// R.info  = depth | includeEmission<<8 | rayType<<9 | (medium+1)<<12   (medium -1 = global)
+// R.info  = depth | includeEmission<<8 | rayType<<9 | (medium+1)<<12   (medium -1 = global); WAPT_INFO_NULL: no task
 // P.info  = light | kind<<16   (kind 0 = directLightHit, 1 = directLightingSingleScatter)
+//
+// What a march sample of volumeScattering() (cpp:429-621) emits goes to slots that follow from the sample's number
+// in its launch - no compaction, no atomics, no barriers: its origin and pixel once (VO[jj]), the bodies of its shadow
+// walks (S.B, S.C, light by light: slot = vol_s1 + (light sample) x vol_ms + jj), of its probes (P.B, P.C, the same
+// way) and its child (R[d+1], slot = first free + number of the sample in the step).  Whatever a sample does not emit
+// is written as an empty entry (length 0, zero direction, WAPT_INFO_NULL), which the kernel that reads it skips.
 #pragma once
 #include "traverse.h"
 
@@ -30,7 +36,8 @@ enum {
     CNT_QV = 3 * WAPT_CNT_STRIDE,         // segments of the current step that scatter (indices into the step)
     CNT_S = 4 * WAPT_CNT_STRIDE,          // shadow-walk tasks
     CNT_P = 5 * WAPT_CNT_STRIDE,          // probe tasks
-    CNT_QM = 6 * WAPT_CNT_STRIDE,         // march samples of the current step ((task, sample) pairs)
+    CNT_QM = 6 * WAPT_CNT_STRIDE,         // march samples of the current step in the open ((segment, sample) pairs)
+    CNT_QMI = 7 * WAPT_CNT_STRIDE,        // march samples of the current step inside an object whose inside scatters
     CNT_R0 = 8 * WAPT_CNT_STRIDE,         // CNT_R(d): tasks in R[d], d = 0..63
     CNT_FEED = (8 + 64) * WAPT_CNT_STRIDE, // 3 x 32 work-feed counters of k_trace, k_shadow and k_probe (zeroed by k_reset)
     CNT_TOTAL = CNT_FEED + 3 * 32 * 64
@@ -51,15 +58,28 @@ struct KScene {
     float wc[3], wr;         // world bound sphere
 };
 
+#define WAPT_INFO_NULL 0xffffffffu  // info word of an R slot that holds no task (a march sample without a child)
+
 struct KQueues {
     float4 *RA, *RB, *RC;    // radiance tasks, depth d at [d*capR, (d+1)*capR)
     float4 *SA, *SB, *SC;
-    float4 *PA, *PB, *PC;
+    float4 *PB, *PC;
+    float4* VO;              // origin | pixel of the march samples of the current launch of the march kernel
     uint2* hits;             // (t bits, triangle) per task of the current step
-    uint32_t* QV;            // tasks of the current step whose segment is marched (scenes with media)
-    uint2* QM;               // their march samples: (task of the step, sample number)
+    // the marched segments of the current step (scenes with media), written by the surface kernel:
+    // A.xyz | length, unit direction | pV, beta.rgb | key, pixel | medium+1, doVol<<30, inside<<31 | march samples | stream
+    float4 *G0, *G1, *G2, *G3;
+    uint2* QM;               // their march samples: (segment, sample number); in the open from the front, inside objects
+                             // from the back of the list
     uint32_t capQM;
+    // the march samples whose shadow walks / probes the current launch of k_shadow / k_probe reads: entry i >= vol_s1
+    // of the shadow queue has its origin in VO[(i - vol_s1) % vol_ms], every entry i of the probe queue in VO[i % vol_ms]
+    // (the division as multiply-and-shift, udiv_magic)
+    uint32_t vol_s1, vol_ms, vol_div_m, vol_div_k;
+    uint32_t vol_scount, vol_pcount;  // entries of the shadow queue beyond vol_s1; entries of the probe queue
     uint32_t capR, capS, capP;
+    uint32_t capSA;          // entries of SA (origins of the walks that the surface kernel sends; the first entries of S)
+    uint32_t capG;           // entries of G0-G3 and of the hit records: tasks of a step
     uint32_t* cnt;           // CNT_*
     unsigned long long* rays;  // closest-hit queries issued by shadow and probe kernels
     float* sum;              // W*H*3 radiance sums

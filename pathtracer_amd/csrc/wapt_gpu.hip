@@ -19,6 +19,22 @@
 #include "kernels.h"
 #include "wapt_internal.h"
 
+// Store of a queue entry by the march kernel: non-temporal (the entries are read once, by a later kernel, long after
+// they have left the caches: march kernel 82.0 -> 78.6 ms per fog frame; WAPT_VOL_NT=0: plain stores).
+#ifndef WAPT_VOL_NT
+#define WAPT_VOL_NT 1
+#endif
+#if WAPT_VOL_NT
+typedef float wapt_vf4 __attribute__((ext_vector_type(4)));
+#define VSTORE(ptr, val)                                                                   \
+    do {                                                                                   \
+        const float4 _v = (val);                                                           \
+        __builtin_nontemporal_store(wapt_vf4{_v.x, _v.y, _v.z, _v.w}, (wapt_vf4*)(ptr));   \
+    } while (0)
+#else
+#define VSTORE(ptr, val) (*(ptr) = (val))
+#endif
+
 // =============================================================== device helpers
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
@@ -38,8 +54,16 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 #ifndef WAPT_VBLOCK
 #define WAPT_VBLOCK 1024
 #endif
+// waves per SIMD of the march kernel: in the open 63 registers, inside objects 70 (64 would spill six)
 #ifndef WAPT_VOLUME_WAVES
-#define WAPT_VOLUME_WAVES 4
+#define WAPT_VOLUME_WAVES 8
+#endif
+#ifndef WAPT_VOLUME_WAVES_IN
+#define WAPT_VOLUME_WAVES_IN 7
+#endif
+// block size of the march kernel proper (no block-wide steps in it)
+#ifndef WAPT_VOLBLOCK
+#define WAPT_VOLBLOCK 256
 #endif
 #ifndef WAPT_PROBE_WAVES
 #define WAPT_PROBE_WAVES 7
@@ -197,13 +221,23 @@ __device__ __forceinline__ uint32_t shadow_target(const DLight& L, int l, V3 wi)
 // A shadow walk from `from` along the unit vector `dir` over the distance `len` (to the sampled light point).
 __device__ __forceinline__ void write_shadow(const KQueues& q, uint32_t slot, V3 from, V3 dir, float len, V3 w, uint32_t pixel,
                                              uint32_t target) {
-    if (slot >= q.capS) {
+    if (slot >= q.capSA) {
         atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
         return;
     }
     q.SA[slot] = make_float4(from.x, from.y, from.z, u2f(pixel));
     q.SB[slot] = make_float4(dir.x, dir.y, dir.z, u2f(target));
     q.SC[slot] = make_float4(w.x, w.y, w.z, len);
+}
+
+// Body of a march sample's shadow walk in its slot (origin and pixel: KQueues::VO); length 0 = no walk.
+__device__ __forceinline__ void write_shadow_body(const KQueues& q, uint32_t slot, bool pred, V3 dir, float len, V3 w, uint32_t target) {
+    if (slot >= q.capS) {
+        atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
+        return;
+    }
+    if (pred) VSTORE(&q.SB[slot], make_float4(dir.x, dir.y, dir.z, u2f(target)));
+    VSTORE(&q.SC[slot], make_float4(w.x, w.y, w.z, pred ? len : 0.f));
 }
 
 __device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from, V3 dir, float len, V3 w, uint32_t pixel,
@@ -213,21 +247,16 @@ __device__ __forceinline__ void push_shadow(const KQueues& q, bool pred, V3 from
     if (pred) write_shadow(q, slot, from, dir, len, w, pixel, target);
 }
 
-__device__ __forceinline__ void write_probe(const KQueues& q, uint32_t slot, V3 o, V3 dir, V3 w, uint32_t pixel, uint32_t info, int medium) {
+// Body of a probe task in its slot (the origin and the pixel are those of its march sample, KQueues::VO); an empty
+// entry (zero direction) for a probe that is not sent.
+__device__ __forceinline__ void write_probe_body(const KQueues& q, uint32_t slot, bool pred, V3 dir, V3 w, uint32_t info, int medium) {
     if (slot >= q.capP) {
         atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
         return;
     }
-    q.PA[slot] = make_float4(o.x, o.y, o.z, u2f(pixel));
-    q.PB[slot] = make_float4(dir.x, dir.y, dir.z, u2f(info));
-    q.PC[slot] = make_float4(w.x, w.y, w.z, u2f((uint32_t)(medium + 1)));
-}
-
-__device__ __forceinline__ void push_probe(const KQueues& q, bool pred, V3 o, V3 dir, V3 w, uint32_t pixel,
-                                           uint32_t info, int medium) {
-    pred = pred && finite_dir(dir) && !is_zero(w);
-    uint32_t slot = block_push(&q.cnt[CNT_P], pred);
-    if (pred) write_probe(q, slot, o, dir, w, pixel, info, medium);
+    if (!pred) dir = v3(0.f, 0.f, 0.f);
+    VSTORE(&q.PB[slot], make_float4(dir.x, dir.y, dir.z, u2f(info)));
+    if (pred) VSTORE(&q.PC[slot], make_float4(w.x, w.y, w.z, u2f((uint32_t)(medium + 1))));
 }
 
 // One task of the current step together with its closest hit.
@@ -300,7 +329,7 @@ __device__ __forceinline__ V3 surface_weight(const KScene& sc, const HitCtx& c) 
 
 __global__ void k_reset(uint32_t* cnt, int r_slot, uint32_t r_value) {
     uint32_t t = threadIdx.x;
-    if (t == 0) cnt[CNT_QV] = cnt[CNT_QM] = cnt[CNT_S] = cnt[CNT_P] = 0u;
+    if (t == 0) cnt[CNT_QV] = cnt[CNT_QM] = cnt[CNT_QMI] = cnt[CNT_S] = cnt[CNT_P] = 0u;
     cnt[CNT_FEED + t * WAPT_FEED_STRIDE] = 0u;  // 96 threads, 96 feed counters (three traversal kernels per step)
     if (r_slot >= 0 && t == 0) cnt[r_slot] = r_value;
 }
@@ -316,10 +345,11 @@ __global__ void k_light_tris(const float4* tris, uint32_t n_tris, int n_lights, 
     if (k == 1) lights[obj].tri1 = (int)i;
 }
 
-// Between two slices of a step's march samples: the shadow and probe queues and the feeds of their kernels start over.
-__global__ void k_reset_sp(uint32_t* cnt) {
+// Between two slices of a step's march samples: the feeds of the shadow and probe kernels start over, and
+// (shadows_too) the shadow queue, once its kernel has run.
+__global__ void k_reset_sp(uint32_t* cnt, int shadows_too) {
     uint32_t t = threadIdx.x;
-    if (t == 0) cnt[CNT_S] = cnt[CNT_P] = 0u;
+    if (t == 0 && shadows_too) cnt[CNT_S] = 0u;
     cnt[CNT_FEED + (32 + t) * WAPT_FEED_STRIDE] = 0u;  // 64 threads: feed counters of k_shadow and k_probe
 }
 
@@ -409,7 +439,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene s
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED);
     Trav t = {};
     bool have = false;
-    uint32_t cur = 0;
+    uint32_t cur = 0, empty = 0;
     const size_t base = (size_t)depth * q.capR + start;
     for (;;) {
         uint32_t idx = feed.take(!have);
@@ -422,11 +452,19 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene s
             } else {
                 float4 a = q.RA[base + idx], b = q.RB[base + idx];
                 trav_begin(t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, WAPT_TFAR);
+                // (a slot that holds no task - a march sample without a child - is taken and dropped)
+                if (f2u(b.w) == WAPT_INFO_NULL) {
+                    empty++;
+                    idx = 0xffffffffu;
+                }
             }
-            cur = idx;
-            have = true;
+            if (idx != 0xffffffffu) {
+                cur = idx;
+                have = true;
+            }
         }
-        if (!__any(have)) break;
+        // (a round whose slots were all empty is no reason to leave while the feed has more)
+        if (!__any(have) && (CAM || feed.exhausted())) break;
         if (trav_step<COUNT, false, WAPT_COOP>(sc.tm, t, have, &s_stack[threadIdx.x], glane, tc, coop)) {
             q.hits[cur] = make_uint2(f2u(t.tmax), t.hit);  // fp32 distance; k_surface refines it
             have = false;
@@ -443,6 +481,10 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_TRACE_WAVES) void k_trace(KScene s
         }
     }
     if (tc.overflow) atomicAdd(&q.cnt[CNT_OVERFLOW], tc.overflow);
+    if (!CAM) {
+        empty = wave_sum(empty);
+        if (lane_id() == 0 && empty) atomicAdd(&q.rays[13], (unsigned long long)empty);
+    }
 }
 
 // Does volumeScattering() march the segment of this task (cpp:221-230, 290, 454)?  A miss is lit through the GLOBAL
@@ -456,6 +498,45 @@ __device__ __forceinline__ bool segment_marched(const KScene& sc, const HitCtx& 
     return medium_of(sc, info_medium(c.info)).scatters != 0u;
 }
 
+// The segment of a task that volumeScattering() marches (cpp:221-230, 290, 429-457).
+struct Segment {
+    V3 A, IBn;
+    float len, pV;
+    bool doVol, inside;
+    int medium;
+    int rms;   // march samples (cpp:457), 0 for a degenerate segment
+};
+
+__device__ __forceinline__ Segment march_segment(const KScene& sc, const KParams& p, const HitCtx& c, int depth) {
+    Segment g;
+    g.A = c.o;
+    V3 B;
+    if (c.tri == 0xffffffffu) {
+        // exit point on the world sphere: the '+' root (cpp:226-227)
+        V3 rel = c.o - ld3(sc.wc);
+        float m = mag(rel);
+        float s1 = 0.f, s2 = 0.f;
+        solve_quadratic(1.0f, 2.0f * dot(rel, c.dir), m * m - sc.wr * sc.wr, &s1, &s2);
+        B = c.o + s1 * c.dir;
+        g.medium = -1;
+        g.inside = false;
+        g.doVol = true;
+        g.pV = 1.0f;
+    } else {
+        B = c.P;
+        g.medium = info_medium(c.info);
+        g.inside = !c.entering;  // objID != -1 (cpp:240-248)
+        g.pV = p_volume(depth);
+        g.doVol = wapt_rand(c.stream, WAPT_DIM_VOL) < g.pV;
+    }
+    V3 IB = B - g.A;
+    g.len = mag(IB);
+    g.IBn = (1.0f / g.len) * IB;
+    g.rms = (int)(g.len * p.mr / ((float)depth + 1.0f)) + 1;  // cpp:457
+    if (!(g.len > 0.f)) g.rms = 0;
+    return g;
+}
+
 // radiance() from the closest hit on (cpp:218-290) for every task of the step, in one pass over the
 // queue: miss handling, roulette, emission, then the surface event of the hit material -
 // Lambert: directReflection (cpp:345-381) + indirectReflection (cpp:383-405); mirror: the specular
@@ -465,7 +546,7 @@ __device__ __forceinline__ bool segment_marched(const KScene& sc, const HitCtx& 
 // out and is bound by that traffic, not by arithmetic: the materials share one kernel (lanes of a wave
 // may run different branches) so that nothing is read twice.
 // ONE: one hemisphere and one light sample per event (the reference's defaults): the sample loops are gone.
-// MEDIA: the scene has a participating medium (hit records are kept and marched segments listed for the march kernel).
+// MEDIA: the scene has a participating medium (marched segments are listed for the march kernel: KQueues::G0-G3).
 // CAM: camera tasks made on the spot, as in k_trace (depth 0 of a scene without media, whole image).
 template <bool ONE, bool MEDIA, bool CAM = false>
 __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
@@ -490,13 +571,15 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
             } else {
                 load_task(q, depth, start, i, c);
             }
+        }
+        // (a slot that holds no task: a march sample that had no child to send, see k_volume)
+        if (valid && (!MEDIA || c.info != WAPT_INFO_NULL)) {
             uint2 h = q.hits[i];
             if (h.y != 0xffffffffu) {
                 // the closest-hit kernel leaves the fp32 distance of its search; the fp64 re-evaluation runs
-                // here, where every lane has a hit to refine (the march kernel reads it back from the queue)
+                // here, where every lane has a hit to refine
                 float tr = refine_distance(sc.tm.tris, h.y, c.o, c.dir, WAPT_TRACE_BIAS, u2f(h.x));
                 h.x = f2u(tr);
-                if (MEDIA) q.hits[i] = h;
             }
             set_hit(sc, h, c);
             DBG(c.pixel, "head d=%d key=%08x o=(%.6f %.6f %.6f) dir=(%.7f %.7f %.7f) t=%.6f tri=%u P=(%.6f %.6f %.6f) obj=%d beta=%g\n", depth, c.key, c.o.x, c.o.y, c.o.z, c.dir.x, c.dir.y, c.dir.z, c.t, c.tri, c.P.x, c.P.y, c.P.z, c.obj, c.beta.x);
@@ -553,6 +636,19 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                 }
             }
         }
+        if (MEDIA) {
+            // the segment goes on the list of the march kernel with everything that kernel needs to know about it
+            uint32_t sv = block_push(&q.cnt[CNT_QV], toV);
+            if (toV) {
+                const Segment g = march_segment(sc, p, c, depth);
+                const bool inside_ok = g.inside && g.medium >= 0;  // (the global medium has no surface of its own to look for)
+                q.G0[sv] = make_float4(g.A.x, g.A.y, g.A.z, g.len);
+                q.G1[sv] = make_float4(g.IBn.x, g.IBn.y, g.IBn.z, g.pV);
+                q.G2[sv] = make_float4(c.beta.x, c.beta.y, c.beta.z, u2f(c.key));
+                q.G3[sv] = make_float4(u2f(c.pixel), u2f((uint32_t)(g.medium + 1) | ((uint32_t)g.doVol << 29) | ((uint32_t)g.inside << 30) | ((uint32_t)inside_ok << 31)),
+                                       u2f((uint32_t)g.rms), u2f(c.stream));
+            }
+        }
         const bool lambert = kind == LAMBERT;
         // Lambert, next event estimation: one shadow walk per light sample
         float rls = 1.0f / (float)lsamples;
@@ -602,50 +698,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
             }
             push_radiance(q, depth + 1, emit, c.P, dir, b, c.pixel, info, key);
         }
-        if (MEDIA) {
-            uint32_t sv = block_push(&q.cnt[CNT_QV], toV);
-            if (toV) q.QV[sv] = i;
-        }
     }
-}
-
-// The segment of a task that volumeScattering() marches (cpp:221-230, 290, 429-457).
-struct Segment {
-    V3 A, IBn;
-    float len, pV;
-    bool doVol, inside;
-    int medium;
-    int rms;   // march samples (cpp:457), 0 for a degenerate segment
-};
-
-__device__ __forceinline__ Segment march_segment(const KScene& sc, const KParams& p, const HitCtx& c, int depth) {
-    Segment g;
-    g.A = c.o;
-    V3 B;
-    if (c.tri == 0xffffffffu) {
-        // exit point on the world sphere: the '+' root (cpp:226-227)
-        V3 rel = c.o - ld3(sc.wc);
-        float m = mag(rel);
-        float s1 = 0.f, s2 = 0.f;
-        solve_quadratic(1.0f, 2.0f * dot(rel, c.dir), m * m - sc.wr * sc.wr, &s1, &s2);
-        B = c.o + s1 * c.dir;
-        g.medium = -1;
-        g.inside = false;
-        g.doVol = true;
-        g.pV = 1.0f;
-    } else {
-        B = c.P;
-        g.medium = info_medium(c.info);
-        g.inside = !c.entering;  // objID != -1 (cpp:240-248)
-        g.pV = p_volume(depth);
-        g.doVol = wapt_rand(c.stream, WAPT_DIM_VOL) < g.pV;
-    }
-    V3 IB = B - g.A;
-    g.len = mag(IB);
-    g.IBn = (1.0f / g.len) * IB;
-    g.rms = (int)(g.len * p.mr / ((float)depth + 1.0f)) + 1;  // cpp:457
-    if (!(g.len > 0.f)) g.rms = 0;
-    return g;
 }
 
 // Slots for `count` consecutive entries per thread (a wave-wide prefix sum of the counts, then as block_push).
@@ -684,7 +737,7 @@ __device__ __forceinline__ uint32_t block_push_count(uint32_t* counter, uint32_t
 // The number of march samples the step's tasks will produce, before any of them is shaded: the launches of a
 // scene with media are sized by bounds on the segment lengths, and a segment inside an OPEN mesh can exceed its
 // bound; the host cuts the step down to what fits if the count says so.  Same arithmetic as k_surface (refined hit
-// distance) and k_expand, so the count is exact.  out[0] += march samples, out[1] += marched segments.
+// distance, march_segment), so the count is exact.  out[0] += march samples, out[1] += marched segments.
 __global__ __launch_bounds__(WAPT_VBLOCK) void k_count(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n,
                                                        unsigned long long* out) {
     unsigned long long mine = 0, segs = 0;
@@ -692,6 +745,7 @@ __global__ __launch_bounds__(WAPT_VBLOCK) void k_count(KScene sc, KQueues q, KPa
         if (i < n) {
             HitCtx c = {};
             load_task(q, depth, start, i, c);
+            if (c.info == WAPT_INFO_NULL) continue;  // (a slot that holds no task)
             uint2 h = q.hits[i];
             if (h.y != 0xffffffffu) h.x = f2u(refine_distance(sc.tm.tris, h.y, c.o, c.dir, WAPT_TRACE_BIAS, u2f(h.x)));
             set_hit(sc, h, c);
@@ -713,165 +767,159 @@ __global__ __launch_bounds__(WAPT_VBLOCK) void k_count(KScene sc, KQueues q, KPa
     }
 }
 
-// One entry (task, sample) per march sample of the step's marched segments: the march kernel then has one
+// One entry (segment, sample) per march sample of the step's marched segments: the march kernel then has one
 // sample per lane, whatever the lengths of the segments (marching a whole segment per lane left most lanes
-// idle: a block ran until its longest segment was done).
-__global__ __launch_bounds__(WAPT_VBLOCK) void k_expand(KScene sc, KQueues q, KParams p, int depth, uint32_t start) {
+// idle: a block ran until its longest segment was done).  Two lists: samples in the open (light sampling, sphere-sampling
+// probes) from the front of QM, samples inside an object whose inside scatters (16 refracted connections per light)
+// from its back; each list is marched by a launch of its own.
+// SPLIT: the scene has such an object.
+template <bool SPLIT>
+__global__ __launch_bounds__(WAPT_VBLOCK) void k_expand(KQueues q) {
     uint32_t n = q.cnt[CNT_QV];
     GRID_LOOP(j, n) {
-        uint32_t i = 0, rms = 0;
+        uint32_t rms = 0;
+        bool in = false;
         if (j < n) {
-            i = q.QV[j];
-            HitCtx c = {};
-            load_task(q, depth, start, i, c);
-            load_hit(sc, q, i, c);
-            rms = (uint32_t)march_segment(sc, p, c, depth).rms;
+            const float4 g3 = q.G3[j];
+            rms = f2u(g3.z);
+            in = SPLIT && (f2u(g3.y) >> 31) != 0u;
         }
-        uint32_t base = block_push_count(&q.cnt[CNT_QM], rms);
-        for (uint32_t s = 0; s < rms; s++)
-            if (base + s < q.capQM) q.QM[base + s] = make_uint2(i, s);  // (the host refuses the step if the count exceeds the list)
+        const uint32_t base = block_push_count(&q.cnt[CNT_QM], in ? 0u : rms);
+        if (!in)
+            for (uint32_t s = 0; s < rms; s++)
+                if (base + s < q.capQM) q.QM[base + s] = make_uint2(j, s);  // (the host refuses the step if the counts exceed the list)
+        if (SPLIT) {
+            const uint32_t ibase = block_push_count(&q.cnt[CNT_QMI], in ? rms : 0u);
+            if (in)
+                for (uint32_t s = 0; s < rms; s++)
+                    if (ibase + s < q.capQM) q.QM[q.capQM - 1u - (ibase + s)] = make_uint2(j, s);
+        }
     }
 }
 
-// volumeScattering (cpp:429-621): one march sample of the segment of one task per lane
-// INSIDE: some object's inside scatters (the 16-probe branch below can be needed)
+// volumeScattering (cpp:429-621): one march sample of one marched segment per lane.  Everything a sample emits goes
+// to slots that follow from its number: jj = its number in this launch, `m0 + jj` its number in its list (see
+// kernels.h), so the kernel has no compaction, no atomics and no barriers.
+// INSIDE: the samples of this launch lie inside an object whose inside scatters (the 16-probe branch, cpp:560-583);
+// else in the open (cpp:487-553), or in the global medium behind a back face (no direct light at all).
+// `kid0`: slot in R[depth + 1] of the child of sample 0 of this launch's list, or 0xffffffff at the last depth.
+// `lights`: the light table (sc.lights) as a parameter of its own that nothing else aliases: the compiler then fetches a
+// light's fields with scalar loads (l is the same in all lanes).  Read through sc.lights inside this loop, which also
+// stores, they are vector loads - the stores might alias - each followed by a wait on the vector-memory counter, and
+// that counter counts the stores too: every light of every march sample waited for all queue writes issued before it.
 template <bool INSIDE>
-__global__ __launch_bounds__(WAPT_VBLOCK, WAPT_VOLUME_WAVES) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t m0, uint32_t n) {
+__global__ __launch_bounds__(WAPT_VOLBLOCK, INSIDE ? WAPT_VOLUME_WAVES_IN : WAPT_VOLUME_WAVES) void k_volume(KScene sc, KQueues q, KParams p, int depth, uint32_t m0, uint32_t n,
+                                                                              uint32_t kid0, const DLight* __restrict__ lights) {
     uint32_t skipped = 0;  // probes decided here (tallied like those k_probe decides)
-    GRID_LOOP(j, n) {
-        const bool act = j < n;
-        HitCtx c = {};
-        Segment g = {};
-        g.IBn = v3(0, 0, 1);
-        g.pV = 1.f;
-        g.medium = -1;
-        int s = 0;
-        if (act) {
-            uint2 e = q.QM[m0 + j];
-            s = (int)e.y;
-            load_task(q, depth, start, e.x, c);
-            load_hit(sc, q, e.x, c);
-            g = march_segment(sc, p, c, depth);
-        }
-        const V3 A = g.A, IBn = g.IBn;
-        const float len = g.len, pV = g.pV;
-        const bool doVol = g.doVol, inside = g.inside;
-        const int medium = g.medium, rms = g.rms;
+    const uint32_t ms = q.vol_ms;
+    for (uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x; jj < n; jj += gridDim.x * blockDim.x) {
+        const uint2 e = INSIDE ? q.QM[q.capQM - 1u - (m0 + jj)] : q.QM[m0 + jj];
+        const int s = (int)e.y;
+        const float4 g0 = q.G0[e.x], g1 = q.G1[e.x], g2 = q.G2[e.x], g3 = q.G3[e.x];
+        const V3 A = v3(g0.x, g0.y, g0.z), IBn = v3(g1.x, g1.y, g1.z), beta = v3(g2.x, g2.y, g2.z);
+        const float len = g0.w, pV = g1.w;
+        const uint32_t key = f2u(g2.w), pixel = f2u(g3.x), gw = f2u(g3.y), stream = f2u(g3.w);
+        const int rms = (int)f2u(g3.z);
+        const int medium = (int)(gw & 0x1fffffffu) - 1;
+        const bool doVol = (gw >> 29) & 1u, inside = (gw >> 30) & 1u;
         const DMaterial& M = medium_of(sc, medium);
-        V3 ss = ld3(M.ss), st = ld3(M.st);
-        // the inside branch looks for the medium's own surface; the global medium has none
-        bool inside_ok = inside && medium >= 0;
-        float rrms = rms > 0 ? 1.0f / (float)rms : 0.f;
+        const V3 ss = ld3(M.ss), st = ld3(M.st);
+        const float rrms = rms > 0 ? 1.0f / (float)rms : 0.f;
+        float x, rpdf_x;
         {
-            float x = 0.f, rpdf_x = 0.f;
-            if (act) {
-                float u = wapt_rand(c.stream, WAPT_DIM_MARCH + (uint32_t)s);
-                if (p.me == 0.0f) {  // wa_samplerBeamUniform (sampling.cpp:75-81)
-                    x = u * len;
-                    rpdf_x = len;
-                } else {  // wa_samplerBeamExponentialAttenuation (sampling.cpp:91-100)
-                    float e = 1.0f - expf(-p.me * len);
-                    x = (-1.0f / p.me) * logf(1.0f - e * u);
-                    rpdf_x = 1.0f / ((p.me / e) * expf(-p.me * x));
+            const float u = wapt_rand(stream, WAPT_DIM_MARCH + (uint32_t)s);
+            if (p.me == 0.0f) {  // wa_samplerBeamUniform (sampling.cpp:75-81)
+                x = u * len;
+                rpdf_x = len;
+            } else {  // wa_samplerBeamExponentialAttenuation (sampling.cpp:91-100)
+                float ee = 1.0f - expf(-p.me * len);
+                x = (-1.0f / p.me) * logf(1.0f - ee * u);
+                rpdf_x = 1.0f / ((p.me / ee) * expf(-p.me * x));
+            }
+        }
+        const V3 S = A + x * IBn;
+        // common factor of everything gathered at S (cpp:611-612) times the scattering albedo and phase
+        const V3 cs = (rpdf_x * rrms * WAPT_PHASE) * (beta * vexp(v3(-st.x * x, -st.y * x, -st.z * x)) * ss);
+        VSTORE(&q.VO[jj], make_float4(S.x, S.y, S.z, u2f(pixel)));
+        // (iii) indirect: one uniform direction, no emission at the next hit (cpp:587-609)
+        if (kid0 != 0xffffffffu) {
+            const uint32_t dim = WAPT_DIM_VCHILD + 2u * (uint32_t)s;
+            const V3 cdir = sphere_uniform(wapt_rand(stream, dim), wapt_rand(stream, dim + 1));
+            const bool cemit = doVol && finite_dir(cdir);
+            const uint32_t slot = kid0 + jj;
+            if (slot >= q.capR) {
+                atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
+            } else {
+                const size_t k = (size_t)(depth + 1) * q.capR + slot;
+                if (cemit) {
+                    const V3 cbeta = ((4.0f * WAPT_PI) / pV) * cs;
+                    VSTORE(&q.RA[k], make_float4(S.x, S.y, S.z, u2f(pixel)));
+                    VSTORE(&q.RB[k], make_float4(cdir.x, cdir.y, cdir.z, u2f(make_info(depth + 1, false, RAY_CAMERA, medium))));
+                    VSTORE(&q.RC[k], make_float4(cbeta.x, cbeta.y, cbeta.z, u2f(wapt_key_child(key, WAPT_SLOT_VOL | (uint32_t)s))));
+                } else {
+                    VSTORE(&q.RB[k], make_float4(0.f, 0.f, 0.f, u2f(WAPT_INFO_NULL)));
                 }
             }
-            V3 S = A + x * IBn;
-            // common factor of everything gathered at S (cpp:611-612) times the scattering albedo and phase
-            V3 cs = (rpdf_x * rrms * WAPT_PHASE) * (c.beta * vexp(v3(-st.x * x, -st.y * x, -st.z * x)) * ss);
-            if (!act) cs = v3(0, 0, 0);
-            float rls = 1.0f / (float)p.lsamples;
-            // (iii) indirect: one uniform direction, no emission at the next hit (cpp:587-609).  The task is
-            // emitted together with the first light's open-air tasks (one compaction for three queues).
-            V3 cdir;
-            bool cemit = act && doVol && (depth + 1 <= p.td);
-            {
-                uint32_t dim = WAPT_DIM_VCHILD + 2u * (uint32_t)s;
-                cdir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
-                cemit = cemit && finite_dir(cdir);
-            }
-            const V3 cbeta = ((4.0f * WAPT_PI) / pV) * cs;
-            const uint32_t cinfo = make_info(depth + 1, false, RAY_CAMERA, medium);
-            const uint32_t ckey = wapt_key_child(c.key, WAPT_SLOT_VOL | (uint32_t)s);
-            bool child_done = false;  // (uniform over the block: set under block-wide votes only)
+        }
+        if (!INSIDE) {
+            // (i) in the open: light sampling and sphere sampling, MIS-weighted (cpp:487-553)
+            const float rls = 1.0f / (float)p.lsamples;
             for (int l = 0; l < sc.n_lights; l++) {
-                const DLight& L = sc.lights[l];
-                {
-                    // (i) in the open: light sampling and sphere sampling, MIS-weighted (cpp:487-553)
-                    for (int k = 0; k < p.lsamples; k++) {
-                        bool emit = false;
-                        V3 LP = v3(0, 0, 0), wt = v3(0, 0, 0);
-                        if (act && !inside) {
-                            uint32_t dim = WAPT_DIM_VNEE + 2u * (uint32_t)((s * sc.n_lights + l) * p.lsamples + k);
-                            float rpdf;
-                            if (light_sample(L, S, v3(0, 0, 0), false, wapt_rand(c.stream, dim),
-                                             wapt_rand(c.stream, dim + 1), &LP, &rpdf)) {
-                                float pdf = 1.0f / rpdf;
-                                float mis = pdf / (pdf + WAPT_MIS_CONST);
-                                if (rpdf == 0.0f) mis = 1.0f;
-                                wt = (rpdf * mis * rls) * (cs * ld3(L.Li));
-                                emit = !is_zero(wt);
-                            }
+                const DLight& L = lights[l];
+                for (int k = 0; k < p.lsamples; k++) {
+                    bool emit = false;
+                    V3 LP = v3(0, 0, 0), wt = v3(0, 0, 0);
+                    if (!inside) {
+                        const uint32_t dim = WAPT_DIM_VNEE + 2u * (uint32_t)((s * sc.n_lights + l) * p.lsamples + k);
+                        float rpdf;
+                        if (light_sample(L, S, v3(0, 0, 0), false, wapt_rand(stream, dim), wapt_rand(stream, dim + 1), &LP, &rpdf)) {
+                            float pdf = 1.0f / rpdf;
+                            float mis = pdf / (pdf + WAPT_MIS_CONST);
+                            if (rpdf == 0.0f) mis = 1.0f;
+                            wt = (rpdf * mis * rls) * (cs * ld3(L.Li));
+                            emit = !is_zero(wt);
                         }
-                        float Wl = 0.f;
-                        const V3 Wi = normalized_len(LP - S, &Wl);
-                        const uint32_t tgt = emit ? shadow_target(L, l, Wi) : 0u;
-                        if (k > 0) {
-                            push_shadow(q, emit, S, Wi, Wl, wt, c.pixel, tgt);
-                            continue;
-                        }
-                        // first light sample, the sphere-sampling probe and (with the first light) the child
-                        // (a light without geometry is never the closest hit of a ray: its probes are not emitted,
-                        //  and their directions - unit vectors, always usable - not even drawn)
-                        const bool reachable = !sc.fast_probe || L.ntri != 0;
-                        const V3 pw = (4.0f * WAPT_PI) * cs;
-                        V3 pdir = v3(0.f, 0.f, 1.f);
-                        if (reachable) {
-                            uint32_t dim = WAPT_DIM_VPROBE + 2u * (uint32_t)(s * sc.n_lights + l);
-                            pdir = sphere_uniform(wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1));
-                        }
-                        uint32_t* const counters[3] = {&q.cnt[CNT_S], &q.cnt[CNT_P], &q.cnt[CNT_R(depth + 1)]};
-                        const bool probe = act && !inside && finite_dir(pdir) && !is_zero(pw);
-                        if (probe && !reachable) skipped++;
-                        const bool preds[3] = {emit, probe && reachable, cemit && !child_done};
-                        uint32_t slots[3];
-                        block_push3(counters, preds, slots);
-                        if (preds[0]) write_shadow(q, slots[0], S, Wi, Wl, wt, c.pixel, tgt);
-                        if (preds[1]) write_probe(q, slots[1], S, pdir, pw, c.pixel, (uint32_t)l, medium);
-                        if (preds[2]) write_radiance(q, depth + 1, slots[2], S, cdir, cbeta, c.pixel, cinfo, ckey);
-                        child_done = true;
                     }
+                    float Wl = 0.f;
+                    const V3 Wi = normalized_len(LP - S, &Wl);
+                    const uint32_t tgt = emit ? shadow_target(L, l, Wi) : 0u;
+                    write_shadow_body(q, q.vol_s1 + (uint32_t)(l * p.lsamples + k) * ms + jj, emit, Wi, Wl, wt, tgt);
                 }
-                if (INSIDE && __syncthreads_or(act && inside_ok)) {
-                    // (ii) inside an object: 16 refracted connections per light (cpp:560-583), three per compaction
-                    V3 toL = normalized(ld3(L.centre) - S);
-                    for (int k0 = 0; k0 < 16; k0 += 3) {
-                        V3 dir[3], pw[3];
-                        bool preds[3];
-#pragma unroll
-                        for (int u = 0; u < 3; u++) {
-                            const int k = k0 + u;
-                            uint32_t dim = WAPT_DIM_VSINGLE + 2u * (uint32_t)((s * sc.n_lights + l) * 16 + k);
-                            float rpdf = 0.f;
-                            dir[u] = v3(0, 0, 1);
-                            if (act && inside_ok && k < 16)
-                                dir[u] = sphere_biased3(toL, 1.5f, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &rpdf);
-                            pw[u] = ((1.0f / 16.0f) * rpdf) * cs;
-                            preds[u] = act && inside_ok && k < 16 && finite_dir(dir[u]) && !is_zero(pw[u]);
-                        }
-                        uint32_t* const counters[3] = {&q.cnt[CNT_P], &q.cnt[CNT_P], &q.cnt[CNT_P]};
-                        uint32_t slots[3];
-                        block_push3(counters, preds, slots);
-#pragma unroll
-                        for (int u = 0; u < 3; u++)
-                            if (preds[u]) write_probe(q, slots[u], S, dir[u], pw[u], c.pixel, (uint32_t)l | (1u << 16), medium);
-                    }
+                // the sphere-sampling probe (a light without geometry is never the closest hit of a ray: its probes are
+                // not sent, and their directions - unit vectors, always usable - not even drawn)
+                const V3 pw = (4.0f * WAPT_PI) * cs;
+                if (L.probe_slot >= 0) {
+                    const uint32_t dim = WAPT_DIM_VPROBE + 2u * (uint32_t)(s * sc.n_lights + l);
+                    const V3 pdir = sphere_uniform(wapt_rand(stream, dim), wapt_rand(stream, dim + 1));
+                    const bool probe = !inside && finite_dir(pdir) && !is_zero(pw);
+                    write_probe_body(q, (uint32_t)L.probe_slot * ms + jj, probe, pdir, pw, (uint32_t)l, medium);
+                } else if (!inside && !is_zero(pw)) {
+                    skipped++;
                 }
             }
-            if (!child_done) push_radiance(q, depth + 1, cemit, S, cdir, cbeta, c.pixel, cinfo, ckey);
+        } else {
+            // (ii) inside an object: 16 refracted connections per light (cpp:560-583)
+            for (int l = 0; l < sc.n_lights; l++) {
+                const DLight& L = lights[l];
+                const V3 toL = normalized(ld3(L.centre) - S);
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t dim = WAPT_DIM_VSINGLE + 2u * (uint32_t)((s * sc.n_lights + l) * 16 + k);
+                    float rpdf = 0.f;
+                    const V3 dir = sphere_biased3(toL, 1.5f, wapt_rand(stream, dim), wapt_rand(stream, dim + 1), &rpdf);
+                    const V3 pw = ((1.0f / 16.0f) * rpdf) * cs;
+                    write_probe_body(q, (uint32_t)(l * 16 + k) * ms + jj, finite_dir(dir) && !is_zero(pw), dir, pw, (uint32_t)l | (1u << 16), medium);
+                }
+            }
         }
     }
     skipped = wave_sum(skipped);
     if (lane_id() == 0 && skipped) atomicAdd(&q.rays[7], (unsigned long long)skipped);
+}
+
+// Number within its launch of the march sample that entry `rel` of a light-by-light block of the shadow or probe queue
+// belongs to (rel % vol_ms; rel < 2^31).
+__device__ __forceinline__ uint32_t vol_sample_of(const KQueues& q, uint32_t rel) {
+    return rel - udiv_by(rel, q.vol_div_m, q.vol_div_k) * q.vol_ms;
 }
 
 // Adds the colours of the lanes with `pred` to their pixels' sums.  The red, green and blue of one pixel
@@ -948,8 +996,13 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
     float4* stage = s_wave[threadIdx.x >> 6].stage;
     CoopLds* coop = &s_wave[threadIdx.x >> 6].coop;
     constexpr bool COOP = PLAIN && WAPT_SHADOW_COOP;
+    // VOL: beyond the walks that the surface kernel sent (entries below s1, with their own origin) the queue can hold the
+    // walks of march samples, whose origin and pixel are their sample's (KQueues::VO)
+    constexpr bool VOL = FOGGY || !PLAIN;
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n = min(q.cnt[CNT_S], q.capS);
+    const bool with_vol = VOL && q.vol_ms != 0u;
+    const uint32_t s1 = with_vol ? q.vol_s1 : min(q.cnt[CNT_S], q.capS);
+    const uint32_t n = with_vol ? s1 + q.vol_scount : s1;
     TraceCount tc = {};
     uint32_t rays = 0;
     const int global_m = sc.n_objects;
@@ -970,7 +1023,9 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
         uint32_t idx = feed.take(!have_task);
         if (idx != 0xffffffffu) {
             WAPT_CHECK_IDX(idx, n, "shadow task");
-            float4 a = q.SA[idx], b = q.SB[idx];
+            float4 a, b = q.SB[idx];
+            if (VOL && idx >= s1) a = q.VO[vol_sample_of(q, idx - s1)];
+            else a = q.SA[idx];
             float4 w4s = q.SC[idx];
             cw = v3(w4s.x, w4s.y, w4s.z);
             cpixel = f2u(a.w);
@@ -1168,7 +1223,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
     float4* astage = s_wave[threadIdx.x >> 6].stage;
     CoopLds* coop = &s_wave[threadIdx.x >> 6].coop;
     uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n = min(q.cnt[CNT_P], q.capP);
+    const uint32_t n = min(q.vol_pcount, q.capP);
     TraceCount tc = {};
     uint32_t rays = 0, decided = 0;
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED + 64 * WAPT_FEED_STRIDE);
@@ -1208,11 +1263,16 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
         uint32_t idx = feed.take(!have_task);
         if (idx != 0xffffffffu) {
             WAPT_CHECK_IDX(idx, n, "probe task");
-            float4 a = q.PA[idx], b = q.PB[idx];
+            const float4 b = q.PB[idx];
             const uint32_t info = f2u(b.w);
             task = idx;
             stage = 0;
-            if ((info >> 16) == 0u) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool sent = b.x != 0.f || b.y != 0.f || b.z != 0.f;  // (an entry with a zero direction is a probe that was not sent)
+            if (sent) a = q.VO[vol_sample_of(q, idx)];
+            if (!sent) {
+                have_task = have_ray = false;
+            } else if ((info >> 16) == 0u) {
                 have_task = have_ray = aim(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), (int)(info & 0xffffu));
             } else {
                 want = 0xffffffffu;
@@ -1292,7 +1352,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
                 }
             }
         }
-        wave_add_rgb(q.sum, astage, lit, lit ? f2u(q.PA[task].w) : 0u, contrib);
+        wave_add_rgb(q.sum, astage, lit, lit ? f2u(q.VO[vol_sample_of(q, task)].w) : 0u, contrib);
     }
     rays = wave_sum(rays);
     decided = wave_sum(decided);
@@ -1424,7 +1484,7 @@ struct wapt_scene {
     unsigned long long* d_rays = nullptr;
     bool all_plain = false, all_plain_foggy = false;
     uint32_t* h_cnt = nullptr;  // pinned
-    unsigned long long* h_u64 = nullptr;  // pinned: 24 ray counters + 2 march-sample counts
+    unsigned long long* h_u64 = nullptr;  // pinned: 24 ray counters + 3 words of the march-sample count
     KQueues kq;
     void* d_queue_block = nullptr;
     size_t queue_bytes = 0;
@@ -1436,6 +1496,7 @@ struct wapt_scene {
     float max_inside = 0.f;    // longest box diagonal of an object whose inside scatters
     bool global_scatters = false;
     int n_lights = 0;
+    int n_reach = 0;  // lights that a probe ray can hit (DLight::probe_slot)
     wapt_camera camera;  // as described by the caller (the progressive interface re-derives lower resolutions from it)
     std::vector<hipEvent_t> ev_pool;
     float* d_sum = nullptr;      // W*H*3 sums of wapt_render (kept between calls)
@@ -1783,6 +1844,15 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     if (desc->n_lights > 0)
         hipLaunchKernelGGL(k_light_tris, dim3((unsigned)((s->n_tris + 255) / 256)), dim3(256), 0, s->stream, (const float4*)s->d_tris,
                            (uint32_t)s->n_tris, desc->n_lights, (DLight*)s->d_lights);
+    // DLight::probe_slot: the lights that a probe ray can have as its closest hit (those with triangles in the tree;
+    // all of them when WAPT_GENERAL_PROBE=1 asks for plain searches), numbered in order
+    if (desc->n_lights > 0) {
+        HIPCHK_S(hipStreamSynchronize(s->stream));
+        HIPCHK_S(hipMemcpy(lights.data(), s->d_lights, lights.size() * sizeof(DLight), hipMemcpyDeviceToHost));
+        const bool general_probe = env_u32("WAPT_GENERAL_PROBE", 0) != 0;
+        for (int i = 0; i < desc->n_lights; i++) lights[i].probe_slot = (general_probe || lights[i].ntri != 0) ? s->n_reach++ : -1;
+        HIPCHK_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    }
 
     hipDeviceProp_t prop;
     HIPCHK_S(hipGetDeviceProperties(&prop, device));
@@ -1795,7 +1865,7 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     HIPCHK_S(hipMalloc((void**)&s->d_rays, 24 * sizeof(unsigned long long)));
     HIPCHK_S(hipMemset(s->d_rays, 0, 24 * sizeof(unsigned long long)));
     HIPCHK_S(hipHostMalloc((void**)&s->h_cnt, CNT_TOTAL * sizeof(uint32_t) + 64));
-    HIPCHK_S(hipHostMalloc((void**)&s->h_u64, 26 * sizeof(unsigned long long)));
+    HIPCHK_S(hipHostMalloc((void**)&s->h_u64, 28 * sizeof(unsigned long long)));
 
     memset(&s->ks, 0, sizeof(s->ks));
     s->ks.tm.nodes = (const uint4*)s->d_nodes;
@@ -1891,10 +1961,10 @@ int ensure_spill(wapt_scene* s) {
 }
 
 // What one task of depth d emits at most.  A task marches one segment: through the global medium (any length up to
-// max_segment) or inside an object (closed objects: no longer than the object's box diagonal); a march sample emits
-// a shadow walk and a probe per light, or 16 probes per light when the segment ends on the object's own back face.  A segment that lies inside an OPEN mesh can
-// exceed that bound: the render loop checks the exact number of march samples of a step before it emits anything
-// and refuses the step then.
+// max_segment) or inside an object (closed objects: no longer than the object's box diagonal); a march sample in the
+// open sends a shadow walk per light sample and a probe per light that has geometry, one inside an object whose inside
+// scatters 16 probes per light.  A segment that lies inside an OPEN mesh can exceed that bound: the render loop checks
+// the exact number of march samples of a step before it emits anything and refuses the step then.
 struct FanOut {
     uint64_t marches, kids, shadows, probes;
 };
@@ -1906,73 +1976,92 @@ FanOut fan_out(const wapt_scene* s, const wapt_render_params* prm, int d) {
     f.marches = std::max(r_out, r_in);
     f.kids = (uint64_t)std::max(prm->hsamples, 1) + f.marches;
     f.shadows = L * prm->lsamples * (1 + f.marches);  // (a segment in an object's medium that ends on a front face samples the lights too)
-    f.probes = L * std::max(r_out, 16 * r_in);
+    f.probes = std::max((uint64_t)s->n_reach * std::max(r_out, r_in), 16 * L * r_in);
     return f;
 }
 
-// (Re)allocates the work queues for a trace depth and a call that issues `paths` top-level tasks.
+// Device memory a render call may use for its queues: five eighths of what is free (its own block included), or
+// WAPT_QUEUE_BUDGET_GB if that is less.
+uint64_t queue_budget(const wapt_scene* s, uint64_t* avail_out) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const uint64_t avail = (uint64_t)(free_b + s->queue_bytes);
+    if (avail_out) *avail_out = avail;
+    uint64_t budget = avail / 8 * 5;
+    if (const char* e = getenv("WAPT_QUEUE_BUDGET_GB")) {
+        const double gb = atof(e);
+        if (gb > 0.0) budget = std::min<uint64_t>(budget, (uint64_t)(gb * 1e9));
+    }
+    return budget;
+}
+
+// (Re)allocates the work queues for a trace depth and a call that issues `paths` top-level tasks; `f0` is the fan-out
+// of a task of depth 0.
 // Capacities: large launches matter more than anything else for the traversal kernels (a launch ends
 // with a tail in which most lanes have run out of work: at 2^22 tasks per launch the lanes of the
 // closest-hit kernel were busy 55 % of the time, at 2^26 90 %; whole frame, dragonChrome 1080p: 2^26 2931,
 // 2^27 3023, 2^28 3055 Mpaths/s; later kernels: 2^28 3400, 2^29 - the 256-spp frame in one piece - 3520), and HBM is
 // plentiful, so the default is 2^29 tasks per depth (24 GiB per depth, 135 GB with the shadow queue and the hit
-// records at td 3) and 2^29 shadow / probe tasks for scenes with media, whose chunks are sized by the
-// worst-case fan-out of a marched segment; all of it is cut down to what the call can use and to five eighths
-// of the free device memory.
-int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task, uint64_t shadows_per_task, uint64_t probes_per_task) {
+// records at td 3); scenes with media get the largest launch that the budget allows, with the queues in the
+// proportions of a task's worst-case fan-out; all of it is cut down to what the call can use and to the budget
+// (queue_budget).
+int ensure_queues(wapt_scene* s, int td, uint64_t paths, const FanOut& f0, int lsamples) {
     int depths = td + 1;
-    uint32_t capR = env_u32("WAPT_RAD_CAP", 1u << 29);
-    // (a marched segment emits one child per march sample: the deeper queues of a scene with media fill up
-    //  from far fewer paths than they have slots)
-    capR = (uint32_t)std::min<uint64_t>(capR, ((paths + 4095) & ~(uint64_t)4095) * std::max<uint64_t>(kids_per_task, 1));
-    capR = std::max(capR, 64u * 64u);
-    capR &= ~63u;
-    uint32_t capS = env_u32("WAPT_SHADOW_CAP", s->has_scatter ? (1u << 29) : capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
-    uint32_t capP = env_u32("WAPT_PROBE_CAP", s->has_scatter ? (1u << 29) : 64u);
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    // Five eighths of what is free (178 GB of an empty GPU).  Scenes without media need 135 GB for a 1080p frame of
-    // 256 spp at td 3 in one piece and should not lose that to a few GB held by others (a process that has just
-    // ended, say); scenes with media take what they are given, their fan-out is bounded by the budget only (fog,
-    // 8 spp: 11.9 Mpaths/s with a quarter, 12.5 with five eighths; dragonMilk 323 -> 343).
-    const uint64_t avail = (uint64_t)(free_b + s->queue_bytes);
-    const uint64_t budget = avail / 8 * 5;
-    if (s->has_scatter) {
-        // A launch of c tasks of depth 0 needs c x kids slots in R[1], c x shadows in S and c x probes in P (and
-        // the deeper launches less): the budget goes to the queues in these proportions, which gives the largest
-        // launch the memory allows (one capacity for all three starves the probe queue of a scene whose rays march
-        // inside an object: 16 probes per light and march sample).
-        const uint64_t kids = std::max<uint64_t>(kids_per_task, 1), sh = std::max<uint64_t>(shadows_per_task, 1),
-                       pr = std::max<uint64_t>(probes_per_task, 1);
-        const uint64_t per_task = (uint64_t)depths * kids * 48 + sh * 48 + pr * 56 + 12 * kids;
+    const uint64_t L = (uint64_t)std::max(s->n_lights, 0);
+    const uint64_t paths_r = (paths + 4095) & ~(uint64_t)4095;
+    const uint64_t budget = queue_budget(s, nullptr);
+    auto cap32 = [](uint64_t v) { return (uint32_t)std::min<uint64_t>(v, 0x7ffff000u); };
+    // capacities in entries: R per depth, S bodies, SA (origins of the surface kernel's walks), P bodies, march samples
+    // of a step (QM, VO), segments / tasks of a step (G0-G3, hit records)
+    uint32_t capR, capS, capSA, capP, capM, capG;
+    if (!s->has_scatter) {
+        capR = env_u32("WAPT_RAD_CAP", 1u << 29);
+        capR = (uint32_t)std::min<uint64_t>(capR, paths_r * std::max<uint64_t>(f0.kids, 1));
+        capR = std::max(capR, 64u * 64u) & ~63u;
+        capS = env_u32("WAPT_SHADOW_CAP", capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
+        auto footprint = [&](uint64_t r, uint64_t sh) { return (uint64_t)depths * r * 48 + sh * 48 + r * 8; };
+        while (footprint(capR, capS) > budget && (capR > (1u << 16) || capS > (1u << 20))) {
+            if (capR > (1u << 16)) capR >>= 1;
+            if (capS > (1u << 20)) capS >>= 1;
+        }
+        capSA = capS;
+        capP = capM = 64u;
+        capG = capR;
+    } else {
+        // A launch of c tasks of depth 0 needs c x kids slots in R[1], c x shadows in S, c x probes in P and c x marches
+        // entries for the march samples (the deeper launches need less per task and are as many tasks larger): the
+        // budget goes to the queues in these proportions, which gives the largest launch the memory allows.
+        const uint64_t kids = std::max<uint64_t>(f0.kids, 1), sh = std::max<uint64_t>(f0.shadows, 1), pr = f0.probes,
+                       ma = std::max<uint64_t>(f0.marches, 1);
+        const uint64_t g_per = 4;  // segments and hit records: the launches of the deepest level are about td + 1 times as large
+        const uint64_t per_task = (uint64_t)depths * kids * 48 + sh * 32 + g_per * L * lsamples * 16 + pr * 32 + ma * 24 + g_per * (64 + 8);
         // (not more than the call can use: its paths x kids tasks is what the second level can hold at most - the
         //  launches of the deeper levels, where most of the work of a low-spp frame is, grow with c too)
-        uint64_t c = std::min<uint64_t>(((paths + 4095) & ~(uint64_t)4095) * kids, budget / per_task);
+        uint64_t c = std::min<uint64_t>(paths_r * kids, budget / per_task);
+        if (const uint32_t rc = env_u32("WAPT_RAD_CAP", 0)) c = std::min<uint64_t>(c, std::max<uint64_t>(rc / kids, 1));
         c = std::max<uint64_t>(c, 4096);
-        auto cap32 = [](uint64_t v) { return (uint32_t)std::min<uint64_t>(v, 0xfffff000u); };
-        capR = std::min(capR, cap32(c * kids)) & ~63u;
+        capR = std::max(cap32(c * kids) & ~63u, 64u * 64u);
         capS = env_u32("WAPT_SHADOW_CAP", cap32(c * sh));
-        capP = env_u32("WAPT_PROBE_CAP", cap32(c * pr));
-    }
-    auto footprint = [&](uint64_t r, uint64_t sh, uint64_t pr) {
-        return (uint64_t)depths * r * 48 + sh * 48 + pr * 56 + r * 12;
-    };
-    while (footprint(capR, capS, capP) > budget && (capR > (1u << 16) || capS > (1u << 20))) {
-        if (capR > (1u << 16)) capR >>= 1;
-        if (capS > (1u << 20)) capS >>= 1;
-        if (capP > (1u << 20)) capP >>= 1;
+        capP = std::max(env_u32("WAPT_PROBE_CAP", cap32(c * pr)), 64u);
+        capM = std::max(cap32(c * ma), 64u);
+        capG = (uint32_t)std::min<uint64_t>(capR, std::max<uint64_t>(c * g_per, 4096));
+        capSA = (uint32_t)std::min<uint64_t>(capS, (uint64_t)capG * std::max<uint64_t>(L * lsamples, 1));
     }
     // A block that is a little smaller than what this call would get is kept (the call runs in slightly smaller
     // chunks): the capacities of a scene with media follow the free memory, which moves between calls (memory of
     // processes that have ended is returned in the background), and hipFree of a block of this size took 0.2-2 s.
     auto enough = [](uint32_t have, uint32_t want) { return have >= want - want / 4; };
-    if (s->d_queue_block && s->queue_depths >= depths && enough(s->capR, capR) && enough(s->capS, capS) && enough(s->capP, capP))
+    if (s->d_queue_block && s->queue_depths >= depths && enough(s->capR, capR) && enough(s->capS, capS) && enough(s->capP, capP) &&
+        enough(s->kq.capSA, capSA) && enough(s->kq.capQM, capM) && enough(s->kq.capG, capG))
         return WAPT_OK;
     if (s->d_queue_block) {
         // keep what an earlier, larger call allocated for the dimensions that do not grow
         capR = std::max(capR, s->capR);
         capS = std::max(capS, s->capS);
         capP = std::max(capP, s->capP);
+        capSA = std::max(capSA, s->kq.capSA);
+        capM = std::max(capM, s->kq.capQM);
+        capG = std::max(capG, s->kq.capG);
         depths = std::max(depths, s->queue_depths);
         HIPCHK(hipFree(s->d_queue_block));
         s->d_queue_block = nullptr;
@@ -1984,14 +2073,14 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
         bytes += (b + 255) & ~(size_t)255;
         return off;
     };
+    const bool media = s->has_scatter;
     size_t oRA = take((size_t)depths * capR * 16), oRB = take((size_t)depths * capR * 16), oRC = take((size_t)depths * capR * 16);
-    size_t oSA = take((size_t)capS * 16), oSB = take((size_t)capS * 16), oSC = take((size_t)capS * 16);
-    size_t oPA = take((size_t)capP * 16), oPB = take((size_t)capP * 16), oPC = take((size_t)capP * 16);
-    size_t oH = take((size_t)capR * 8);
-    size_t oQV = take(s->has_scatter ? (size_t)capR * 4 : 256);
-    // (task, sample) pairs of the march kernel: a task has no more march samples than probes
-    const uint32_t capQM = s->has_scatter ? capP : 32u;
-    size_t oQM = take((size_t)capQM * 8);
+    size_t oSA = take((size_t)capSA * 16), oSB = take((size_t)capS * 16), oSC = take((size_t)capS * 16);
+    size_t oPB = take((size_t)capP * 16), oPC = take((size_t)capP * 16);
+    size_t oH = take((size_t)capG * 8);
+    size_t oQM = take((size_t)capM * 8), oVO = take((size_t)capM * 16);
+    const size_t gN = media ? capG : 16;
+    size_t oG0 = take(gN * 16), oG1 = take(gN * 16), oG2 = take(gN * 16), oG3 = take(gN * 16);
     HIPCHK(hipMalloc(&s->d_queue_block, bytes));
     char* b = (char*)s->d_queue_block;
     KQueues& q = s->kq;
@@ -2001,15 +2090,20 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, uint64_t kids_per_task,
     q.SA = (float4*)(b + oSA);
     q.SB = (float4*)(b + oSB);
     q.SC = (float4*)(b + oSC);
-    q.PA = (float4*)(b + oPA);
     q.PB = (float4*)(b + oPB);
     q.PC = (float4*)(b + oPC);
     q.hits = (uint2*)(b + oH);
-    q.QV = (uint32_t*)(b + oQV);
     q.QM = (uint2*)(b + oQM);
-    q.capQM = capQM;
+    q.VO = (float4*)(b + oVO);
+    q.G0 = (float4*)(b + oG0);
+    q.G1 = (float4*)(b + oG1);
+    q.G2 = (float4*)(b + oG2);
+    q.G3 = (float4*)(b + oG3);
+    q.capQM = capM;
+    q.capG = capG;
     q.capR = capR;
     q.capS = capS;
+    q.capSA = capSA;
     q.capP = capP;
     q.cnt = s->d_cnt;
     q.rays = s->d_rays;
@@ -2080,7 +2174,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     const uint64_t n_paths = (uint64_t)((cam.resI + 7) / 8) * (uint64_t)((cam.resJ + 7) / 8) * 64u * (uint64_t)prm->sample_count;
     {
         const FanOut f0 = fan_out(s, prm, 0);
-        int rc = ensure_queues(s, prm->max_depth, n_paths, f0.kids, f0.shadows, f0.probes);
+        int rc = ensure_queues(s, prm->max_depth, n_paths, f0, prm->lsamples);
         if (rc) return rc;
     }
     KScene ks = s->ks;  // (after ensure_queues: it sets the spill area and stack capacity of ks.tm)
@@ -2116,14 +2210,16 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     const dim3 grid(s->grid), block(WAPT_BLOCK);
     const dim3 sgrid(s->sgrid), sblock(WAPT_SBLOCK);
     const dim3 vgrid(s->cus * env_u32("WAPT_VBLOCKS_PER_CU", 2048u / WAPT_VBLOCK)), vblock(WAPT_VBLOCK);
+    const dim3 volgrid(s->cus * env_u32("WAPT_VOLBLOCKS_PER_CU", 2048u / WAPT_VOLBLOCK)), volblock(WAPT_VOLBLOCK);
 
     // fan-out of one task of depth d (sizes the chunk taken from R[d])
     const int L = s->n_lights;
     auto chunk_for = [&](int d) -> uint32_t {
         const FanOut f = fan_out(s, prm, d);
-        uint64_t c = s->capR;
+        uint64_t c = std::min(s->capR, s->kq.capG);
         if (d < td) c = std::min<uint64_t>(c, s->capR / f.kids);
         if (f.shadows) c = std::min<uint64_t>(c, s->capS / f.shadows);
+        if (L > 0) c = std::min<uint64_t>(c, s->kq.capSA / ((uint64_t)L * prm->lsamples));
         if (f.probes) c = std::min<uint64_t>(c, s->capP / f.probes);
         if (f.marches) c = std::min<uint64_t>(c, s->kq.capQM / f.marches);
         return (uint32_t)c;
@@ -2147,7 +2243,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     std::vector<uint32_t> have((size_t)td + 2, 0u);
     const unsigned long long total = (unsigned long long)kp.slots_per_sample * (unsigned long long)prm->sample_count;
     unsigned long long issued = 0;
-    uint64_t rays_trace = 0, n_trace_launches = 0, n_shadow_launches = 0;
+    uint64_t rays_trace = 0, n_trace_launches = 0, n_shadow_launches = 0, empties_seen = 0, empties_kept = 0;
     bool aborted = false;
     HIPCHK(hipMemsetAsync(s->d_rays, 0, 24 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(96), 0, st, s->d_cnt, CNT_OVERFLOW, 0u);
@@ -2203,10 +2299,13 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
             unsigned long long* h_m = s->h_u64 + 24;  // (a copy into pageable memory goes through the runtime's staging path)
             HIPCHK(hipMemsetAsync(s->d_rays + 14, 0, 2 * sizeof(unsigned long long), st));
             tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_count, vgrid, vblock, 0, st, ks, q, kp, d, start, n, s->d_rays + 14); });
-            HIPCHK(hipMemcpyAsync(h_m, s->d_rays + 14, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h_m, s->d_rays + 13, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            const uint64_t M = h_m[0], kids_surface = (uint64_t)n * (uint64_t)std::max(prm->hsamples, 1);
+            const uint64_t M = h_m[1], kids_surface = (uint64_t)n * (uint64_t)std::max(prm->hsamples, 1);
             const bool fits = M <= s->kq.capQM && (d >= td || kids_surface + M <= s->capR);
+            // (slots without a task that the closest-hit launch met: those of a launch that is repeated do not count)
+            if (fits) empties_kept += h_m[0] - empties_seen;
+            empties_seen = h_m[0];
             if (fits) break;
             if (n <= 64)
                 return wapt_fail(WAPT_E_LIMIT, "the march samples of 64 tasks (" + std::to_string(M) + ") do not fit the queues");
@@ -2230,69 +2329,100 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
             else if (!kp.write_hits) hipLaunchKernelGGL((k_surface<false, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
             else hipLaunchKernelGGL((k_surface<false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
         });
-        auto run_shadow = [&] {
+        // the walks of the shadow queue: those the surface kernel sent and, beyond the first s1 entries, `vol_count` entries
+        // of the march samples of the current slice (vol_ms samples, or 0: no such entries, the queue counter says it all)
+        auto run_shadow = [&](uint32_t s1, uint32_t vol_ms, uint32_t vol_count) {
+            KQueues qs = q;
+            qs.vol_s1 = s1;
+            qs.vol_ms = vol_ms;
+            qs.vol_scount = vol_count;
+            if (vol_ms) udiv_magic(vol_ms, &qs.vol_div_m, &qs.vol_div_k);
             tm.run(FAM_SHADOW, [&] {
                 if (s->all_plain) {
-                    if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, ks, q);
-                    else hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, ks, q);
+                    if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, true>), grid, block, 0, st, ks, qs);
+                    else hipLaunchKernelGGL((k_shadow<false, true>), grid, block, 0, st, ks, qs);
                 } else if (s->all_plain_foggy) {
-                    if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, true, true>), grid, block, 0, st, ks, q);
-                    else hipLaunchKernelGGL((k_shadow<false, true, true>), grid, block, 0, st, ks, q);
+                    if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, true, true>), grid, block, 0, st, ks, qs);
+                    else hipLaunchKernelGGL((k_shadow<false, true, true>), grid, block, 0, st, ks, qs);
                 } else {
-                    if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, ks, q);
-                    else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, ks, q);
+                    if (prm->profile & 2) hipLaunchKernelGGL((k_shadow<true, false>), grid, block, 0, st, ks, qs);
+                    else hipLaunchKernelGGL((k_shadow<false, false>), grid, block, 0, st, ks, qs);
                 }
             });
+            n_shadow_launches++;
         };
+        bool shadows_pending = true;  // (what the surface kernel sent)
+        uint64_t kids_total = 0;
         if (s->has_scatter) {
-            // The march samples of the step are counted before any of them emits: the step's queues were sized by
+            // The march samples of the step are listed before any of them emits: the step's queues were sized by
             // bounds (fan_out), the counts are exact.  The samples are marched in slices that fit the shadow and probe
-            // queues (normally one), each followed by the kernels that drain those queues.
-            tm.run(FAM_VOLUME, [&] { hipLaunchKernelGGL(k_expand, vgrid, vblock, 0, st, ks, q, kp, d, start); });
+            // queues (normally one per list), each followed by the kernels that drain those queues.
+            tm.run(FAM_VOLUME, [&] {
+                if (s->has_inside) hipLaunchKernelGGL(k_expand<true>, vgrid, vblock, 0, st, q);
+                else hipLaunchKernelGGL(k_expand<false>, vgrid, vblock, 0, st, q);
+            });
             HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            const uint64_t M = s->h_cnt[CNT_QM];
+            const uint64_t M_out = s->h_cnt[CNT_QM], M_in = s->h_cnt[CNT_QMI], M = M_out + M_in;
             uint64_t s_used = std::min(s->h_cnt[CNT_S], s->capS);
             const uint64_t kids_now = d < td ? s->h_cnt[CNT_R(d + 1)] : 0;
             if (M > s->kq.capQM || (d < td && kids_now + M > s->capR))
                 return wapt_fail(WAPT_E_LIMIT, "a step has more march samples (" + std::to_string(M) +
                                                    ") than the queues were sized for: a segment inside an object is longer than the object's box");
+            kids_total = kids_now + (d < td ? M : 0);
             const uint64_t sh_per = (uint64_t)L * prm->lsamples;
-            const uint64_t pr_per = (uint64_t)L * (s->has_inside ? 16 : 1);
-            uint64_t m0 = 0;
-            while (m0 < M) {
-                uint64_t ms = M - m0;
-                if (sh_per) ms = std::min(ms, (s->capS - s_used) / sh_per);
-                if (pr_per) ms = std::min(ms, (uint64_t)s->capP / pr_per);
-                if (ms == 0) {
-                    if (s_used == 0) return wapt_fail(WAPT_E_LIMIT, "shadow queue smaller than the fan-out of one march sample");
-                    run_shadow();  // make room: drain what the surface kernel emitted
-                    hipLaunchKernelGGL(k_reset_sp, dim3(1), dim3(64), 0, st, s->d_cnt);
-                    s_used = 0;
-                    continue;
-                }
-                tm.run(FAM_VOLUME, [&] {
-                    if (s->has_inside) hipLaunchKernelGGL(k_volume<true>, vgrid, vblock, 0, st, ks, q, kp, d, start, (uint32_t)m0, (uint32_t)ms);
-                    else hipLaunchKernelGGL(k_volume<false>, vgrid, vblock, 0, st, ks, q, kp, d, start, (uint32_t)m0, (uint32_t)ms);
-                });
-                tm.run(FAM_PROBE, [&] {
-                    if (prm->profile & 2) hipLaunchKernelGGL(k_probe<true>, grid, block, 0, st, ks, q);
-                    else hipLaunchKernelGGL(k_probe<false>, grid, block, 0, st, ks, q);
-                });
-                m0 += ms;
-                if (m0 < M) {
-                    run_shadow();
-                    hipLaunchKernelGGL(k_reset_sp, dim3(1), dim3(64), 0, st, s->d_cnt);
-                    s_used = 0;
+            for (int inside = 0; inside < 2; inside++) {
+                const uint64_t Ml = inside ? M_in : M_out;
+                const uint64_t pr_per = inside ? (uint64_t)L * 16 : (uint64_t)s->n_reach;
+                uint64_t m0 = 0;
+                while (m0 < Ml) {
+                    uint64_t ms = Ml - m0;
+                    if (!inside && sh_per) ms = std::min(ms, (s->capS - s_used) / sh_per);
+                    if (pr_per) ms = std::min(ms, (uint64_t)s->capP / pr_per);
+                    if (ms == 0) {
+                        if (inside || s_used == 0) return wapt_fail(WAPT_E_LIMIT, "shadow or probe queue smaller than the fan-out of one march sample");
+                        run_shadow((uint32_t)s_used, 0u, 0u);  // make room: drain what the surface kernel sent
+                        hipLaunchKernelGGL(k_reset_sp, dim3(1), dim3(64), 0, st, s->d_cnt, 1);
+                        s_used = 0;
+                        shadows_pending = false;
+                        continue;
+                    }
+                    KQueues qv = q;
+                    qv.vol_s1 = (uint32_t)s_used;
+                    qv.vol_ms = (uint32_t)ms;
+                    udiv_magic(qv.vol_ms, &qv.vol_div_m, &qv.vol_div_k);
+                    qv.vol_scount = inside ? 0u : (uint32_t)(ms * sh_per);
+                    qv.vol_pcount = (uint32_t)(ms * pr_per);
+                    const uint32_t kid0 = d < td ? (uint32_t)(kids_now + (inside ? M_out : 0) + m0) : 0xffffffffu;
+                    tm.run(FAM_VOLUME, [&] {
+                        if (inside) hipLaunchKernelGGL(k_volume<true>, volgrid, volblock, 0, st, ks, qv, kp, d, (uint32_t)m0, (uint32_t)ms, kid0, ks.lights);
+                        else hipLaunchKernelGGL(k_volume<false>, volgrid, volblock, 0, st, ks, qv, kp, d, (uint32_t)m0, (uint32_t)ms, kid0, ks.lights);
+                    });
+                    if (qv.vol_pcount)
+                        tm.run(FAM_PROBE, [&] {
+                            if (prm->profile & 2) hipLaunchKernelGGL(k_probe<true>, grid, block, 0, st, ks, qv);
+                            else hipLaunchKernelGGL(k_probe<false>, grid, block, 0, st, ks, qv);
+                        });
+                    m0 += ms;
+                    // (the walks read their origins from the slice's samples: they run before the next slice is marched)
+                    if (!inside) {
+                        run_shadow((uint32_t)s_used, (uint32_t)ms, qv.vol_scount);
+                        s_used = 0;
+                        shadows_pending = false;
+                    }
+                    hipLaunchKernelGGL(k_reset_sp, dim3(1), dim3(64), 0, st, s->d_cnt, shadows_pending ? 0 : 1);
                 }
             }
         }
-        run_shadow();
-        n_shadow_launches++;
+        if (shadows_pending) run_shadow(0u, 0u, 0u);
         if (d < td) {
-            HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            have[d + 1] = std::min(s->h_cnt[CNT_R(d + 1)], s->capR);
+            if (s->has_scatter) {
+                have[d + 1] = (uint32_t)std::min<uint64_t>(kids_total, s->capR);
+            } else {
+                HIPCHK(hipMemcpyAsync(s->h_cnt, s->d_cnt, CNT_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                have[d + 1] = std::min(s->h_cnt[CNT_R(d + 1)], s->capR);
+            }
         }
     }
     unsigned long long* h_rays = s->h_u64;
@@ -2304,6 +2434,7 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->paths = (uint64_t)W * H * (uint64_t)prm->sample_count;
+        rays_trace -= s->has_inside ? empties_kept : h_rays[13];  // (slots of the deeper queues that held no task)
         stats->rays = rays_trace + h_rays[0] + h_rays[3];
         stats->stack_overflows = s->h_cnt[CNT_OVERFLOW] + s->h_cnt[CNT_QOVERFLOW];
         stats->seconds = std::chrono::duration<double>(t1 - t0).count();
