@@ -86,13 +86,20 @@ WAPT_HD V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
 
 // ---- device-side scene records --------------------------------------------
 
-struct DMaterial {
-    float kd[3], ks[3], kt[3], ss[3], st[3];
-    float ior;
+// What the kernels read of a wa_shader (src/objects.h:13-41), in four 16-byte words; a surface event reads the first two.
+struct __attribute__((aligned(16))) DMaterial {
+    float kcol[3];        // the colour its surface event multiplies by: kd of a diffuse material, ks of any other
+                          // (cpp:313-343: a diffuse shader never reads ks, a specular or dielectric one never kd)
     uint32_t flags;
-    uint32_t scatters;  // !isClear && ss != 0: volumeScattering does work (cpp:454)
-    float pad[2];
-};  // 80 B
+    float ior;
+    uint32_t kt_nonzero;  // kt != 0 (transmission(), cpp:298)
+    uint32_t scatters;    // !isClear && ss != 0: volumeScattering does work (cpp:454)
+    uint32_t pad0;
+    float st[3];
+    float pad1;
+    float ss[3];
+    float pad2;
+};  // 64 B
 
 struct DLight {
     int32_t type;

@@ -48,6 +48,10 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 #ifndef WAPT_SURFACE_WAVES
 #define WAPT_SURFACE_WAVES 6
 #endif
+// 1: the surface kernel reserves the slots of a task's child and of its first shadow walk in one step (see k_surface)
+#ifndef WAPT_SURFACE_MERGE
+#define WAPT_SURFACE_MERGE 1
+#endif
 // block size of the march kernel (113 registers, 4 waves per SIMD: one block of 1024 threads per CU).  The kernel's
 // time follows the number of block-wide queue reservations, not the occupancy: fog scene, ms per 2-spp frame,
 // 264 / 152 / 135 with blocks of 256 / 512 / 1024 threads.
@@ -308,10 +312,19 @@ __device__ __forceinline__ void load_hit(const KScene& sc, const KQueues& q, uin
 __device__ __forceinline__ float p_surface(int depth) { return 1.0f / (0.125f * (float)depth + 1.0f); }
 __device__ __forceinline__ float p_volume(int depth) { return 1.0f / (0.04f * (float)depth + 1.0f); }
 
-// beta * attenuation(medium0, P0->hit) / pS: the factor on everything the surface event returns (cpp:283-286)
-__device__ __forceinline__ V3 surface_weight(const KScene& sc, const HitCtx& c) {
-    const DMaterial& m0 = medium_of(sc, info_medium(c.info));
-    V3 w = c.beta * attenuation(m0, mag(c.P - c.o));
+// beta * attenuation(medium0, P0->hit) / pS: the factor on everything the surface event returns (cpp:283-286).
+// `gflags`, `gst`: flags and extinction of the global medium (the medium of most tasks), held by the caller.
+__device__ __forceinline__ V3 surface_weight(const DMaterial* __restrict__ mats, const HitCtx& c, uint32_t gflags, V3 gst) {
+    const int med = info_medium(c.info);
+    uint32_t f0 = gflags;
+    if (med >= 0) f0 = mats[med].flags;
+    V3 w = c.beta;
+    if (!(f0 & WAPT_MAT_CLEAR)) {
+        V3 st = gst;
+        if (med >= 0) st = ld3(mats[med].st);
+        const float dist = mag(c.P - c.o);
+        w = w * vexp(v3(-st.x * dist, -st.y * dist, -st.z * dist));
+    }
     return (1.0f / p_surface(info_depth(c.info))) * w;
 }
 
@@ -548,10 +561,18 @@ __device__ __forceinline__ Segment march_segment(const KScene& sc, const KParams
 // ONE: one hemisphere and one light sample per event (the reference's defaults): the sample loops are gone.
 // MEDIA: the scene has a participating medium (marched segments are listed for the march kernel: KQueues::G0-G3).
 // CAM: camera tasks made on the spot, as in k_trace (depth 0 of a scene without media, whole image).
+// `mats`, `lights`: the material and light tables (sc.mats, sc.lights) as parameters of their own that nothing else
+// aliases.  Read through the scene structure, every field was a vector load of its own at its point of use, each
+// followed by a wait for all vector-memory operations in flight - a dozen dependent round trips per task; said this
+// way the compiler may gather a task's loads, and fetches the fields of light l (the same in all lanes) with scalar loads.
 template <bool ONE, bool MEDIA, bool CAM = false>
-__global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n) {
+__global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KScene sc, KQueues q, KParams p, int depth, uint32_t start, uint32_t n,
+                                                                              const DMaterial* __restrict__ mats, const DLight* __restrict__ lights) {
     const int lsamples = ONE ? 1 : p.lsamples, hsamples = ONE ? 1 : p.hsamples;
     enum { NONE, LAMBERT, MIRROR, DIELECTRIC };
+    // the global medium, in which most tasks travel
+    const uint32_t gflags = mats[sc.n_objects].flags;
+    const V3 gst = ld3(mats[sc.n_objects].st);
     GRID_LOOP(i, n) {
         const bool valid = i < n;
         HitCtx c = {};
@@ -586,24 +607,28 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
             if (c.tri == 0xffffffffu) {
                 if (MEDIA) toV = segment_marched(sc, c);
             } else {
-                const DMaterial& m = sc.mats[c.obj];
+                // the first two words of the hit object's material, in one go: colour | flags, ior | kt != 0 | scatters
+                const float4* mp = (const float4*)(mats + c.obj);
+                const float4 ma = mp[0], mb = mp[1];
+                const uint32_t mflags = f2u(ma.w);
+                const V3 kcol = v3(ma.x, ma.y, ma.z);
                 float xs = wapt_rand(c.stream, WAPT_DIM_SURF);
                 if (xs < p_surface(depth)) {
-                    w = surface_weight(sc, c);
+                    w = surface_weight(mats, c, gflags, gst);
                     if (info_emit(c.info) && c.obj < sc.n_lights)
-                        add_rgb(q.sum, c.pixel, w * ld3(sc.lights[c.obj].Li));  // primitive.cpp:21-29
-                    if (m.flags & WAPT_MAT_DIFFUSE) kind = LAMBERT;
-                    else if (m.flags & WAPT_MAT_SPECULAR) kind = MIRROR;
-                    else if (m.flags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) kind = DIELECTRIC;
+                        add_rgb(q.sum, c.pixel, w * ld3(lights[c.obj].Li));  // primitive.cpp:21-29
+                    if (mflags & WAPT_MAT_DIFFUSE) kind = LAMBERT;
+                    else if (mflags & WAPT_MAT_SPECULAR) kind = MIRROR;
+                    else if (mflags & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) kind = DIELECTRIC;
                 }
                 if (MEDIA) toV = segment_marched(sc, c);
                 N1f = c.entering ? c.N : -c.N;
                 if (kind == LAMBERT) {
-                    kd = ld3(m.kd);
+                    kd = kcol;
                 } else if (kind == MIRROR) {
                     if (info_raytype(c.info) != RAY_DIFFUSE && depth + 1 <= p.td) {
                         cdir = reflect_dir(-c.dir, N1f);
-                        cb = w * ld3(m.ks);
+                        cb = w * kcol;
                         cinfo = make_info(depth + 1, info_emit(c.info), RAY_SPECULAR, info_medium(c.info));
                         ckey = wapt_key_child(c.key, WAPT_SLOT_SPEC);
                         cemit = true;
@@ -611,12 +636,12 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                 } else if (kind == DIELECTRIC) {
                     V3 D = -c.dir;
                     float F;
-                    V3 D2 = refract_dir(c.N, D, m.ior, &F);
+                    V3 D2 = refract_dir(c.N, D, mb.x, &F);
                     float pR = (1.0f - WAPT_BLEND) * 0.5f + WAPT_BLEND * F;
                     bool transmit = wapt_rand(c.stream, WAPT_DIM_DIEL) < (1.0f - pR);
                     if (depth + 1 <= p.td) {
                         if (transmit) {
-                            bool kt_nonzero = m.kt[0] != 0.f || m.kt[1] != 0.f || m.kt[2] != 0.f;
+                            const bool kt_nonzero = f2u(mb.y) != 0u;
                             if (kt_nonzero && !is_zero(D2)) {
                                 cdir = -D2;
                                 cb = ((1.0f - F) / (1.0f - pR)) * w;
@@ -627,7 +652,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                             }
                         } else if (info_raytype(c.info) != RAY_DIFFUSE) {
                             cdir = reflect_dir(D, N1f);
-                            cb = (F / pR) * (w * ld3(m.ks));
+                            cb = (F / pR) * (w * kcol);
                             cinfo = make_info(depth + 1, info_emit(c.info), RAY_SPECULAR, info_medium(c.info));
                             ckey = wapt_key_child(c.key, WAPT_SLOT_SPEC);
                             cemit = true;
@@ -650,6 +675,32 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
             }
         }
         const bool lambert = kind == LAMBERT;
+        const bool deeper = lambert && (depth + 1 <= p.td);
+        // ONE: the event's single child is made first and parked in LDS (this thread's own entry), so that its slot
+        // can be reserved together with the slot of the first light's shadow walk: one block-wide reservation (a pair
+        // of barriers around an atomic whose answer the whole block waits for) per task instead of two.
+        __shared__ float4 s_child[WAPT_SURFACE_MERGE ? 2 * WAPT_SBLOCK : 1];
+        bool child_emit = false;
+        constexpr bool MERGE = ONE && WAPT_SURFACE_MERGE;
+        if (MERGE) {
+            V3 dir = cdir, b = cb;
+            uint32_t info = cinfo, key = ckey;
+            child_emit = cemit;
+            if (deeper) {
+                dir = hemisphere_uniform(N1f, wapt_rand(c.stream, WAPT_DIM_HEMI), wapt_rand(c.stream, WAPT_DIM_HEMI + 1u));
+                float ndw = dot(dir, N1f);
+                if (!(ndw < 0.0f)) {
+                    b = ((1.0f / WAPT_PI) * ndw * (2.0f * WAPT_PI)) * (w * kd);
+                    info = make_info(depth + 1, false, RAY_DIFFUSE, info_medium(c.info));
+                    key = wapt_key_child(c.key, WAPT_SLOT_HEMI);
+                    child_emit = true;
+                }
+            }
+            child_emit = child_emit && finite_dir(dir);
+            s_child[threadIdx.x] = make_float4(dir.x, dir.y, dir.z, u2f(info));
+            s_child[WAPT_SBLOCK + threadIdx.x] = make_float4(b.x, b.y, b.z, u2f(key));
+        }
+        bool child_pending = MERGE;
         // Lambert, next event estimation: one shadow walk per light sample
         float rls = 1.0f / (float)lsamples;
         for (int l = 0; l < sc.n_lights; l++) {
@@ -661,7 +712,7 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                 if (lambert) {
                     uint32_t dim = WAPT_DIM_NEE + 2u * (uint32_t)(l * lsamples + s);
                     float rpdf;
-                    const DLight& L = sc.lights[l];
+                    const DLight& L = lights[l];
                     if (light_sample(L, c.P, N1f, true, wapt_rand(c.stream, dim), wapt_rand(c.stream, dim + 1), &LP, &rpdf)) {
                         Wi = normalized_len(LP - c.P, &Wl);
                         float ndw = dot(Wi, N1f);
@@ -674,12 +725,31 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                     }
                     DBG(c.pixel, "nee d=%d key=%08x emit=%d LP=(%.5f %.5f %.5f) wt=%g\n", depth, c.key, (int)emit, LP.x, LP.y, LP.z, wt.x);
                 }
+                if (MERGE && l == 0) {
+                    uint32_t* const counters[3] = {&q.cnt[CNT_S], &q.cnt[CNT_R(depth + 1)], &q.cnt[CNT_R(depth + 1)]};
+                    const bool preds[3] = {emit && !is_zero(wt), child_emit, false};
+                    uint32_t slots[3];
+                    block_push3(counters, preds, slots);
+                    if (preds[0]) write_shadow(q, slots[0], c.P, Wi, Wl, wt, c.pixel, tgt);
+                    if (preds[1]) {
+                        const float4 cd = s_child[threadIdx.x], cbk = s_child[WAPT_SBLOCK + threadIdx.x];
+                        write_radiance(q, depth + 1, slots[1], c.P, v3(cd.x, cd.y, cd.z), v3(cbk.x, cbk.y, cbk.z), c.pixel, f2u(cd.w), f2u(cbk.w));
+                    }
+                    child_pending = false;
+                    continue;
+                }
                 push_shadow(q, emit, c.P, Wi, Wl, wt, c.pixel, tgt);
             }
         }
+        if (MERGE) {
+            if (child_pending) {  // (a scene without lights)
+                const float4 cd = s_child[threadIdx.x], cbk = s_child[WAPT_SBLOCK + threadIdx.x];
+                push_radiance(q, depth + 1, child_emit, c.P, v3(cd.x, cd.y, cd.z), v3(cbk.x, cbk.y, cbk.z), c.pixel, f2u(cd.w), f2u(cbk.w));
+            }
+            continue;
+        }
         // children: hsamples uniform hemisphere directions of a Lambert event (no emission at the next
         // hit), or the single continuation of a mirror / dielectric event
-        const bool deeper = lambert && (depth + 1 <= p.td);
         float rhs = 1.0f / (float)hsamples;
         for (int s = 0; s < hsamples; s++) {
             bool emit = cemit && s == 0;
@@ -1516,9 +1586,8 @@ uint32_t env_u32(const char* name, uint32_t def) {
 DMaterial to_device(const wapt_material& m) {
     DMaterial d;
     memset(&d, 0, sizeof(d));
-    memcpy(d.kd, m.kd, 12);
-    memcpy(d.ks, m.ks, 12);
-    memcpy(d.kt, m.kt, 12);
+    memcpy(d.kcol, (m.flags & WAPT_MAT_DIFFUSE) ? m.kd : m.ks, 12);
+    d.kt_nonzero = (m.kt[0] != 0.f || m.kt[1] != 0.f || m.kt[2] != 0.f) ? 1u : 0u;
     memcpy(d.ss, m.ss, 12);
     memcpy(d.st, m.st, 12);
     d.ior = m.ior;
@@ -2322,12 +2391,12 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         tm.run(FAM_SHADE, [&] {
             const bool one = prm->lsamples == 1 && prm->hsamples == 1;
             const bool cam = fuse_camera && d == 0;
-            if (cam && one) hipLaunchKernelGGL((k_surface<true, false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
-            else if (cam) hipLaunchKernelGGL((k_surface<false, false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
-            else if (one && !kp.write_hits) hipLaunchKernelGGL((k_surface<true, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
-            else if (one) hipLaunchKernelGGL((k_surface<true, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
-            else if (!kp.write_hits) hipLaunchKernelGGL((k_surface<false, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
-            else hipLaunchKernelGGL((k_surface<false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n);
+            if (cam && one) hipLaunchKernelGGL((k_surface<true, false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n, ks.mats, ks.lights);
+            else if (cam) hipLaunchKernelGGL((k_surface<false, false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n, ks.mats, ks.lights);
+            else if (one && !kp.write_hits) hipLaunchKernelGGL((k_surface<true, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n, ks.mats, ks.lights);
+            else if (one) hipLaunchKernelGGL((k_surface<true, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n, ks.mats, ks.lights);
+            else if (!kp.write_hits) hipLaunchKernelGGL((k_surface<false, false>), sgrid, sblock, 0, st, ks, q, kp, d, start, n, ks.mats, ks.lights);
+            else hipLaunchKernelGGL((k_surface<false, true>), sgrid, sblock, 0, st, ks, q, kp, d, start, n, ks.mats, ks.lights);
         });
         // the walks of the shadow queue: those the surface kernel sent and, beyond the first s1 entries, `vol_count` entries
         // of the march samples of the current slice (vol_ms samples, or 0: no such entries, the queue counter says it all)
