@@ -331,8 +331,16 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
         t.sp--;
         WAPT_CHECK_IDX(t.sp, m.stack_cap, "stack pointer (pop)");
         WAPT_CHECK_IDX(glane, m.spill_stride > 0u ? m.spill_stride : 0xffffffffu, "lane of the launch");
-        t.G = (t.sp < WAPT_LDS_STACK) ? lds[t.sp * WAPT_BLOCK]
-                                      : m.spill[(size_t)(t.sp - WAPT_LDS_STACK) * m.spill_stride + glane];
+        // (two separate loads: written as one conditional expression the compiler selects between the two ADDRESSES
+        //  and issues a flat load, which is slower than an LDS read and is waited for together with every vector-memory
+        //  operation the wave has in flight - the hit record it has just stored, for one)
+        if (t.sp < WAPT_LDS_STACK) {
+            t.G = lds[t.sp * WAPT_BLOCK];
+            asm volatile("" : "+v"(t.G.x), "+v"(t.G.y));  // (keeps the two loads apart)
+        } else {
+            const uint2* sp_ = m.spill + ((size_t)(t.sp - WAPT_LDS_STACK) * m.spill_stride + glane);
+            t.G = *sp_;
+        }
     }
     if (descend) {
         // all ones where the ray runs down the axis (the sign of the reciprocal: it is never zero)
