@@ -79,6 +79,20 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 // (One returning atomic per wave on a single counter tops out near 90 per microsecond on this
 // chip, far below what the streaming kernels need; one per block is 12x fewer.)
 // Every thread of the block must call this together.
+// Inclusive prefix sums within every row of 16 lanes, by moves between the lanes' registers (a lane without a source
+// lane adds zero).  The block's first wave runs this between two barriers that every other wave waits at.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t row_scan_u(uint32_t x) {
+    x += dpp_u<0x111>(x);  // row_shr 1
+    x += dpp_u<0x112>(x);  // row_shr 2
+    x += dpp_u<0x114>(x);  // row_shr 4
+    x += dpp_u<0x118>(x);  // row_shr 8
+    return x;
+}
+
 __device__ __forceinline__ uint32_t block_push(uint32_t* counter, bool pred) {
     __shared__ uint32_t s_cnt[16];
     __shared__ uint32_t s_off[16];
@@ -90,16 +104,11 @@ __device__ __forceinline__ uint32_t block_push(uint32_t* counter, bool pred) {
     __syncthreads();
     if (wave == 0) {
         uint32_t c = lane < nw ? s_cnt[lane] : 0u;
-        uint32_t x = c;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            uint32_t y = __shfl_up(x, o);
-            if ((int)lane >= o) x += y;
-        }
-        uint32_t total = __shfl(x, (int)nw - 1);
+        const uint32_t x = row_scan_u(c);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)x, 15);  // (lanes from nw on hold zero)
         uint32_t base = 0;
         if (lane == 0 && total) base = atomicAdd(counter, total);
-        base = __shfl(base, 0);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (lane < nw) s_off[lane] = base + x - c;
     }
     __syncthreads();
@@ -125,17 +134,14 @@ __device__ __forceinline__ void block_push3(uint32_t* const counter[3], const bo
     if (wave == 0) {
         const uint32_t qi = lane >> 4, w = lane & 15u;
         uint32_t c = (qi < 3u && w < nw) ? s_cnt3[qi][w] : 0u;
-        uint32_t x = c;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            uint32_t y = __shfl_up(x, o, 16);
-            if ((int)w >= o) x += y;
-        }
-        uint32_t total = __shfl(x, 15, 16);
+        const uint32_t x = row_scan_u(c);
+        // the row's total sits in its last lane, which takes the atomic; the answer goes back to the row
         uint32_t base = 0;
         uint32_t* cp = qi == 0u ? counter[0] : (qi == 1u ? counter[1] : counter[2]);
-        if (w == 15u && qi < 3u && total) base = atomicAdd(cp, total);
-        base = __shfl(base, 15, 16);
+        if (w == 15u && qi < 3u && x) base = atomicAdd(cp, x);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)base, 15), b1 = (uint32_t)__builtin_amdgcn_readlane((int)base, 31),
+                       b2 = (uint32_t)__builtin_amdgcn_readlane((int)base, 47);
+        base = qi == 0u ? b0 : (qi == 1u ? b1 : b2);
         if (qi < 3u && w < nw) s_off3[qi][w] = base + x - c;
     }
     __syncthreads();
@@ -154,6 +160,28 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+
+// Sum of v over the 64 lanes of the wave, the same value in every lane.  Data-parallel-primitive moves between the
+// lanes' registers (pairs, quads, rotations within a row of 16, then the rows' last lanes handed on) instead of six
+// round trips through the LDS crossbar: the pixel sums of the shadow kernels are on the path of every loop trip
+// (shadow kernel of dragonChrome 33.5 -> ... ms per frame with them).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_total_f(float v) {
+    v += dpp_f<0xb1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4e>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x124>(v);  // row_ror 4
+    v += dpp_f<0x128>(v);  // row_ror 8: every lane holds the sum of its row of 16
+    v += dpp_f<0x142>(v);  // row_bcast 15: plus the sum of the row before (rows 1 and 3 are what matters)
+    v += dpp_f<0x143>(v);  // row_bcast 31: rows 2 and 3 plus what lane 31 holds; lane 63 now has the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+#ifndef WAPT_ADD_PASSES
+#define WAPT_ADD_PASSES 2
+#endif
 
 __device__ __forceinline__ void add_rgb(float* sum, uint32_t pixel, V3 c) {
     float* p = sum + (size_t)pixel * 3;
@@ -998,24 +1026,29 @@ __device__ __forceinline__ uint32_t vol_sample_of(const KQueues& q, uint32_t rel
 // instruction per channel takes three.  `stage` is 64 float4 of LDS owned by the calling wave; all lanes
 // of the wave call this together.
 __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pred, uint32_t pixel, V3 c) {
+#ifdef WAPT_EXP_NOADD
+    asm volatile("" ::"v"(pixel), "v"(c.x), "v"(c.y), "v"(c.z));
+    return;
+#endif
     unsigned long long m = __ballot(pred);
     if (m == 0ull) return;
     uint32_t lane = lane_id();
-    // Tasks ordered pixel by pixel: most lanes of a wave hold samples of ONE pixel.  The lanes on the pixel of the
-    // first of them are summed across the wave (three sums, one request); what is left goes the general way.
-    {
-        const uint32_t px0 = (uint32_t)__shfl((int)pixel, __ffsll((long long)m) - 1);
+    // Tasks ordered pixel by pixel: most lanes of a wave hold samples of ONE pixel, or of two.  The lanes on the pixel
+    // of the first of them are summed across the wave (three sums in the lanes' own registers, wave_total_f; one
+    // request), twice if need be; what is left goes the general way.
+#pragma unroll
+    for (int pass = 0; pass < WAPT_ADD_PASSES; pass++) {
+        const uint32_t px0 = (uint32_t)__builtin_amdgcn_readlane((int)pixel, __ffsll((long long)m) - 1);
         const bool maj = pred && pixel == px0;
-        if (__popcll(__ballot(maj)) > 2) {
-            const float r = wave_sum_f(maj ? c.x : 0.f), g = wave_sum_f(maj ? c.y : 0.f), b = wave_sum_f(maj ? c.z : 0.f);
-            if (lane < 3u) {
-                const float v = lane == 0u ? r : lane == 1u ? g : b;
-                if (v != 0.f) unsafeAtomicAdd(sum + (size_t)px0 * 3 + lane, v);
-            }
-            pred = pred && !maj;
-            m = __ballot(pred);
-            if (m == 0ull) return;
+        if (__popcll(__ballot(maj)) <= 2) break;
+        const float r = wave_total_f(maj ? c.x : 0.f), g = wave_total_f(maj ? c.y : 0.f), b = wave_total_f(maj ? c.z : 0.f);
+        if (lane < 3u) {
+            const float v = lane == 0u ? r : lane == 1u ? g : b;
+            if (v != 0.f) unsafeAtomicAdd(sum + (size_t)px0 * 3 + lane, v);
         }
+        pred = pred && !maj;
+        m = __ballot(pred);
+        if (m == 0ull) return;
     }
     if (pred) {
         uint32_t at = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -1077,6 +1110,9 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
     uint32_t rays = 0;
     const int global_m = sc.n_objects;
     const bool gclear = (sc.mats[global_m].flags & WAPT_MAT_CLEAR) != 0u;
+    // (the global medium's extinction, fetched once: read where it is used, inside the loop, it is two dependent vector
+    //  loads - flags, then coefficients - per trip, each waited for on the spot)
+    const V3 gst = FOGGY ? ld3(sc.mats[global_m].st) : v3(0.f, 0.f, 0.f);
     WaveFeed feed = wave_feed(n, q.cnt + CNT_FEED + 32 * WAPT_FEED_STRIDE);
     Trav t = {};
     bool have_task = false, have_ray = false;
@@ -1140,7 +1176,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             if (PLAIN && cut) {
                 lit = !blocked && tri == 0xffffffffu;
                 blocked = !lit;
-                if (FOGGY && lit) V = attenuation(sc.mats[global_m], ABl);
+                if (FOGGY && lit) V = gclear ? v3(1.f, 1.f, 1.f) : vexp(v3(-gst.x * ABl, -gst.y * ABl, -gst.z * ABl));
             } else if (PLAIN) {
                 if (!blocked) {
                     bool at_target = false;
@@ -1172,7 +1208,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
                             seg = dot(t.d, N) < 0.0f ? dd : 0.0f;
                         }
                     }
-                    if (FOGGY && lit && seg > 0.0f) V = attenuation(sc.mats[global_m], seg);
+                    if (FOGGY && lit && seg > 0.0f) V = gclear ? v3(1.f, 1.f, 1.f) : vexp(v3(-gst.x * seg, -gst.y * seg, -gst.z * seg));
                 }
             } else if (!blocked) {
                 const bool in_clear = gclear && cur == global_m;
