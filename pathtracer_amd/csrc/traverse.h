@@ -32,6 +32,10 @@
 #ifndef WAPT_SHADOW_WAVES
 #define WAPT_SHADOW_WAVES 7
 #endif
+// the general shadow kernel (walks through media and transparent surfaces)
+#ifndef WAPT_SHADOW_WAVES_GENERAL
+#define WAPT_SHADOW_WAVES_GENERAL 7
+#endif
 
 // Last word of a triangle record: flags of its object in the low byte, the object index above.
 #define WAPT_TRI_OPAQUE 1u   // the object is opaque: a shadow walk that meets it before its end point is over

@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
 // is then over with its first search - nothing is passed through, nothing attenuates: blocked if the search stopped
 // at a surface before B or its closest hit lies before B - TRACE_BIAS, arrived otherwise (cpp:764-778 with V = 1).
 template <bool COUNT, bool PLAIN, bool FOGGY = false>
-__global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene sc, KQueues q) {
+__global__ __launch_bounds__(WAPT_BLOCK, PLAIN ? WAPT_SHADOW_WAVES : WAPT_SHADOW_WAVES_GENERAL) void k_shadow(KScene sc, KQueues q) {
     __shared__ uint2 s_stack[WAPT_LDS_STACK * WAPT_BLOCK];
     __shared__ union WaveLds {
         float4 stage[64];
@@ -1123,6 +1123,8 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
     int cur = global_m, it = 0;
     uint32_t target = 0;
     bool cut = false;  // the search of this walk ends short of B (see below)
+    uint32_t ctask = 0;   // general form: the task, whose weight is read again when the walk arrives (its walks are long,
+                          // and three registers less keep the kernel out of scratch memory at 7 waves per SIMD)
     V3 cw = v3(0, 0, 0);  // weight and pixel of the task (read with it: a read at the walk's end is a memory round trip
     uint32_t cpixel = 0;  // that the whole wave waits for, 4 % of the kernel)
     for (;;) {
@@ -1133,7 +1135,8 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
             if (VOL && idx >= s1) a = q.VO[vol_sample_of(q, idx - s1)];
             else a = q.SA[idx];
             float4 w4s = q.SC[idx];
-            cw = v3(w4s.x, w4s.y, w4s.z);
+            if (PLAIN) cw = v3(w4s.x, w4s.y, w4s.z);
+            else ctask = idx;
             cpixel = f2u(a.w);
             ABl = w4s.w;  // (direction and length come with the task: the kernel that sampled the light point had them)
             t.o = v3(a.x, a.y, a.z);
@@ -1288,6 +1291,10 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_SHADOW_WAVES) void k_shadow(KScene
         if (lit) {
             pixel = cpixel;
             WAPT_CHECK_IDX(pixel, (uint32_t)(sc.cam.resI * sc.cam.resJ), "pixel of a shadow task");
+            if (!PLAIN) {
+                const float4 w4 = q.SC[ctask];
+                cw = v3(w4.x, w4.y, w4.z);
+            }
             contrib = cw * V;
             DBG(pixel, "shadow lit V=%g w=%g d=%.6f ABl=%.6f\n", V.x, cw.x, d, ABl);
         }
@@ -1342,28 +1349,12 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
     uint32_t want = 0xffffffffu;
     int want_light = 0;
 
-    // Starts the search of a ray whose closest hit has to be light `l`, or decides it on the spot.
-    auto aim = [&](V3 o, V3 d, int l) -> bool {
-        const DLight& L = sc.lights[l];
-        want = 0xffffffffu;
-        want_light = l;
-        if (sc.fast_probe && L.ntri == 0) {
-            decided++;
-            return false;
-        }
-        if (sc.fast_probe && L.ntri == 2) {
-            float tl;
-            if (!quad_hit(sc.tm.tris, (uint32_t)L.tri0, (uint32_t)L.tri1, o, d, WAPT_TRACE_BIAS, WAPT_TFAR, &tl, &want)) {
-                decided++;
-                return false;
-            }
-            trav_begin(t, o, d, WAPT_TRACE_BIAS, tl);  // nothing beyond the quad matters
-        } else {
-            trav_begin(t, o, d, WAPT_TRACE_BIAS, WAPT_TFAR);
-        }
-        rays++;
-        return true;
-    };
+    // The lane has a ray to aim at light `want_light`, its origin and direction in t.o / t.d: a new directLightHit probe,
+    // or the refracted second ray of a single-scatter probe.  The search is started - or the query decided on the spot -
+    // at ONE place of the loop, below.  (With the start written out at both places, ROCm 7.2's compiler merged the
+    // copies and lost the assignment of the new direction to t.d on one of the merged paths - the second ray was then
+    // searched along the first ray's direction; tests/test_gpu_render.py::test_dragon_milk_same_seed shows it.)
+    bool aim_pending = false;
 
     for (;;) {
         uint32_t idx = feed.take(!have_task);
@@ -1379,13 +1370,34 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
             if (!sent) {
                 have_task = have_ray = false;
             } else if ((info >> 16) == 0u) {
-                have_task = have_ray = aim(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), (int)(info & 0xffffu));
+                t.o = v3(a.x, a.y, a.z);
+                t.d = v3(b.x, b.y, b.z);
+                want_light = (int)(info & 0xffffu);
+                aim_pending = true;
+                have_task = true;
+                have_ray = false;
             } else {
                 want = 0xffffffffu;
                 trav_begin(t, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), WAPT_TRACE_BIAS, WAPT_TFAR);
                 have_task = have_ray = true;
                 rays++;
             }
+        }
+        if (aim_pending) {
+            // Starts the search of a ray whose closest hit has to be light `want_light`, or decides it on the spot.
+            aim_pending = false;
+            const DLight& L = sc.lights[want_light];
+            const V3 o = t.o, d = t.d;
+            bool started = true;
+            want = 0xffffffffu;
+            float tfar = WAPT_TFAR;
+            if (sc.fast_probe && L.ntri == 0) started = false;
+            else if (sc.fast_probe && L.ntri == 2)   // nothing beyond the quad matters
+                started = quad_hit(sc.tm.tris, (uint32_t)L.tri0, (uint32_t)L.tri1, o, d, WAPT_TRACE_BIAS, WAPT_TFAR, &tfar, &want);
+            if (started) trav_begin(t, o, d, WAPT_TRACE_BIAS, tfar);
+            have_task = have_ray = started;
+            rays += started ? 1u : 0u;
+            decided += started ? 0u : 1u;
         }
         // (a round whose tasks were all finished on the spot is no reason to leave while the feed has more; the
         //  rest of the loop body does nothing then)
@@ -1453,7 +1465,11 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
                         seg0 = mag(hp - S);
                         F0 = F;
                         stage = 1;
-                        have_task = have_ray = aim(hp, dir1, light);
+                        t.o = hp;
+                        t.d = dir1;
+                        want_light = light;
+                        aim_pending = true;  // (the lane keeps its task; the second search starts at the top of the next trip)
+                        have_task = true;
                     }
                 }
             }
