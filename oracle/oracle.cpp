@@ -22,7 +22,11 @@
 //  * Random numbers: the reference shares one std::default_random_engine
 //    between four threads without a lock (src/randomnumbers.cpp:11,30-41) and
 //    cannot reproduce its own images.  The checker uses the same keyed hash as
-//    the GPU library (restated below) so both draw identical samples.
+//    the GPU library (restated below) so both draw identical samples.  A second
+//    mode (OParams::profile bit 2) draws every number from a std::mt19937_64 of
+//    the rendering thread instead, one after the other in call order - the
+//    reference's own scheme without its race: a generator that shares nothing
+//    with the keyed hash, to check the hash against.
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
@@ -30,6 +34,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <thread>
 #include <vector>
 
@@ -107,7 +112,10 @@ static inline uint32_t key_root(uint64_t seed, uint32_t sample) {
 }
 static inline uint32_t key_child(uint32_t key, uint32_t slot) { return fmix32(mix32(key, slot) ^ 0x9e3779b9u); }
 static inline uint32_t stream_of(uint32_t key, uint32_t pixel) { return mix32(key, pixel); }
+// sequential mode: the generator of the calling thread (null: keyed numbers)
+static thread_local std::mt19937_64* tl_sequential = nullptr;
 static inline float rnd(uint32_t stream, uint32_t dim) {
+    if (tl_sequential) return (float)((*tl_sequential)() >> 40) * (1.0f / 16777216.0f);  // randFloat, randomnumbers.cpp:30-41
     return (float)(fmix32(mix32(stream, dim)) >> 8) * (1.0f / 16777216.0f);
 }
 enum { DIM_FIXED = 0u << 20, DIM_HEMI = 1u << 20, DIM_NEE = 2u << 20, DIM_MARCH = 3u << 20, DIM_VNEE = 4u << 20,
@@ -943,6 +951,9 @@ int oracle_render(const oracle_scene* s, const OParams* p, float* fb, int thread
         th.emplace_back([&, t]() {
             tl_rays = 0;
             tl_shadow_rays = 0;
+            // profile bit 2: every number from this thread's own generator, in call order (see the header)
+            std::mt19937_64 sequential(p->seed * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull * (uint64_t)(t + 1));
+            tl_sequential = (p->profile & 4) ? &sequential : nullptr;
             Renderer R;
             R.sc = s;
             R.hs = p->hsamples;
@@ -968,6 +979,7 @@ int oracle_render(const oracle_scene* s, const OParams* p, float* fb, int thread
                 }
             rays += tl_rays;
             g_shadow_rays += tl_shadow_rays;
+            tl_sequential = nullptr;
         });
     for (auto& x : th) x.join();
     if (rays_out) *rays_out = rays.load();

@@ -64,7 +64,9 @@ class OracleScene:
         return hits
 
     def render(self, psamples, hsamples=1, lsamples=1, td=None, me=None, mr=None, seed=0, threads=8,
-               sample_begin=0, sample_count=None):
+               sample_begin=0, sample_count=None, sequential=False):
+        """sequential: every random number from a std::mt19937_64 per rendering thread, drawn in call order, instead
+        of the keyed hash that the GPU library shares (the image then depends on the thread count)."""
         sc = self.scene
         p = abi.RenderParams()
         p.psamples, p.hsamples, p.lsamples = psamples, hsamples, lsamples
@@ -74,6 +76,7 @@ class OracleScene:
         p.seed = seed
         p.sample_begin = sample_begin
         p.sample_count = psamples if sample_count is None else sample_count
+        p.profile = 4 if sequential else 0
         W, H = sc.resolution
         fb = np.zeros((H, W, 3), np.float32)
         rays = C.c_uint64()

@@ -62,11 +62,13 @@ def test_two_area_lights_facing_each_other_clear_air_two_samples_per_event():
     same_seed_check(_two_lights_facing(res=(96, 96), fog=False), 16, hsamples=2, lsamples=2)
 
 
-def _converged(scene, name, spp=4096, ref_spp=1024, light_lum=5.0):
+def _converged(scene, name, spp=4096, ref_spp=1024, light_lum=5.0, sequential=False):
+    """sequential: the checker's two renders draw from a std::mt19937_64 per thread instead of the keyed hash that
+    it shares with the library - an estimate that has nothing in common with the GPU's but the estimator."""
     fb, st = gpu_render(scene, spp, seed=11)
     o = oracle_api.OracleScene(scene)
-    a = o.render(ref_spp, seed=12, threads=16)
-    b = o.render(ref_spp, seed=13, threads=16)
+    a = o.render(ref_spp, seed=12, threads=16, sequential=sequential)
+    b = o.render(ref_spp, seed=13, threads=16, sequential=sequential)
     ref = 0.5 * (a + b)
     mask = ref.mean(-1) < light_lum  # leave the directly visible light out, as the noise floor figure does
     noise = helpers.rel_rmse(a, b, mask)
@@ -75,7 +77,10 @@ def _converged(scene, name, spp=4096, ref_spp=1024, light_lum=5.0):
     expect = np.sqrt((1.0 / spp + 0.5 / ref_spp) / (2.0 / ref_spp))
     print(f"{name}: noise({ref_spp} vs {ref_spp}) {noise:.4f}  gpu{spp} vs checker{2 * ref_spp} {err:.4f}  expected {expect * noise:.4f}")
     assert err <= expect * noise * 1.5
-    np.testing.assert_allclose(fb[mask].mean(0), ref[mask].mean(0), rtol=5e-3)
+    # image means: 0.5 %, or three standard errors of the mean of that many pixels where the image is noisier than that
+    # (the fog scene with the area light: 9 % between two 1024-spp renders, light sampled at 1 / distance^2)
+    mean_rtol = max(5e-3, 3.0 * expect * noise / np.sqrt(mask.sum()))
+    np.testing.assert_allclose(fb[mask].mean(0), ref[mask].mean(0), rtol=mean_rtol)
     assert st.stack_overflows == 0
 
 
@@ -89,3 +94,15 @@ def test_converged_chrome():
 
 def test_converged_glass_td6():
     _converged(scenes.dragon("glass", res=(96, 54), td=6, n_along=200, n_around=60), "glass")
+
+
+def test_converged_fog_sphere_lights_against_an_independent_generator():
+    _converged(scenes.fog(res=(16, 12)), "fog, sphere lights", sequential=True)
+
+
+def test_converged_fog_area_light_against_an_independent_generator():
+    _converged(scenes.fog(res=(16, 12), lights="area"), "fog, area light", sequential=True)
+
+
+def test_converged_milk_against_an_independent_generator():
+    _converged(scenes.dragon("milk", res=(24, 14), n_along=120, n_around=40), "milk", sequential=True)

@@ -46,7 +46,7 @@ def test_gpu_matches_the_published_images_above_the_objects():
     n = 600
     fb, _ = _render(scenes.cornell(res=(n, n), spheres=False), 1024, seed=5)
     tm = np.clip(np.power(np.maximum(fb, 0), 0.45), 0, 1) * 255.0  # myRenderer.cpp:174-185, 713
-    for name in ("dragonChrome.bmp", "cornellBox.bmp", "dragonGlass.bmp", "dragonMilk.bmp"):
+    for name in ("dragonChrome.bmp", "cornellBox.bmp", "dragonGlass.bmp", "dragonMilk.bmp", "dragonKetchup.bmp"):
         lit, dim = [], []
         for p in g["images"][name]["patches"]:
             i, j = int(p["col"]), n - 1 - int(p["row"])  # image row 0 is the top, frame buffer row 0 the bottom

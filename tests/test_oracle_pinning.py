@@ -46,7 +46,7 @@ def test_known_answers_of_the_reference_estimator(empty_box_1024):
 
 def test_published_images_above_the_objects():
     """Tone-mapped oracle render of the empty box against the published dragonChrome / cornellBox / dragonGlass /
-    dragonMilk renders in rows 0..250 (the objects below change the indirect light there by a few per cent; the
+    dragonMilk / dragonKetchup renders in rows 0..250 (the objects below change the indirect light there by a few per cent; the
     published images themselves differ by 3-12 % from each other in that region)."""
     g = json.load(open(os.path.join(GOLD, "published_image_patches.json")))
     n = 150
@@ -54,7 +54,7 @@ def test_published_images_above_the_objects():
     fb = oracle_api.OracleScene(sc).render(128, seed=5, threads=8)
     tm = np.clip(np.power(np.maximum(fb, 0), 0.45), 0, 1) * 255.0  # myRenderer.cpp:174-185, 713
     scale = n / 600.0
-    for name in ("dragonChrome.bmp", "cornellBox.bmp", "dragonGlass.bmp", "dragonMilk.bmp"):
+    for name in ("dragonChrome.bmp", "cornellBox.bmp", "dragonGlass.bmp", "dragonMilk.bmp", "dragonKetchup.bmp"):
         lit, dim = [], []
         for p in g["images"][name]["patches"]:
             i = int(p["col"] * scale)

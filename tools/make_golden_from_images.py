@@ -34,7 +34,7 @@ def main(src, dst):
            "images": {}}
     cols = [40, 100, 170, 300, 430, 500, 560]
     rows = [20, 130, 200, 245]
-    for name in ["cornellBox.bmp", "dragonChrome.bmp", "dragonGlass.bmp", "dragonMilk.bmp"]:
+    for name in ["cornellBox.bmp", "dragonChrome.bmp", "dragonGlass.bmp", "dragonMilk.bmp", "dragonKetchup.bmp"]:
         img = read_bmp(f"{src}/{name}").astype(np.float64)
         patches = []
         for r in rows:
