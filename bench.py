@@ -17,23 +17,25 @@ Work per step
   --total-spp T         one image of T samples whatever N is.
 
 Rank 0 prints one JSON line.  `value` is whole-job Mpaths/s (a path = one pixel sample = one top-level radiance()
-call).  `roofline` prices the dominant kernel, the closest-hit traversal k_trace:
-  * the bound that holds it is VALU issue, not HBM (the 52 MB tree is served by L2 and Infinity Cache).  A wave64
-    vector instruction occupies its SIMD for 2 cycles if it is an f32 add / mul / fma, a two-operand logic operation,
-    an integer add or a move, for 4 if it is anything else (min / max, compares, selects, conversions, shifts ...) and
-    for 8 if it is a transcendental (measured: tools/probes/valu_rate.hip, profiles/valu_issue_cost.txt).  So
-    `achieved` is VALU issue cycles per second = (issue cycles per ray) x rays per second in the kernel (HIP events on
-    the library's stream), against `peak` = 1024 SIMDs x 2.4 GHz; issue cycles per ray = the kernel's instruction
-    counters by class (SQ_INSTS_VALU_FMA_F32, _MUL_F32, _ADD_F32, _CVT, _TRANS_F32), each at its cost, plus the
-    instructions no class counter breaks out at the mean cost of such instructions in the kernel's ISA
-    (profiles/valu_issue_mix.json, `make -C pathtracer_amd/csrc isa`).  `insts_frac_at_2_cycles` is the same
-    instruction count priced as if every instruction took 2 cycles (a lower bound of the utilisation);
-  * the algorithmic byte rate (32 B ray + 8 B hit + 80 B x node visits + 48 B x triangle tests per ray, the visit counts
-    measured by the counting build of the same kernel on the same rays) is given against L2 and against HBM;
-  * `traffic` is the kernel's memory-side bytes per launch from the FETCH_SIZE / WRITE_SIZE counters.
-The counters are collected by THIS run: before the parent process touches the GPU it runs `rocprofv3 --pmc` three times
-(one counter group each, no tracing) over a child that renders one frame of the same workload; if that fails the line
-says so and replays the committed profile of the round, tagged with its source.
+call).  `roofline` describes the dominant kernel, the closest-hit traversal k_trace, with the three figures that
+bound it side by side:
+  * `frac` = `achieved` / `peak`: the kernel's memory-side traffic (FETCH_SIZE + WRITE_SIZE counters, bytes per launch
+    in `traffic`) over its average launch time (HIP events on the library's stream) against the 8 TB/s of HBM;
+  * `algorithmic`: 32 B ray + 8 B hit + 80 B x node visits + 48 B x triangle tests per ray (the visit counts measured by
+    the counting build of the same kernel on the same rays) x rays per second.  For a tree that fits the caches
+    (dragonChrome: 52 MB) this rate EXCEEDS the HBM peak - the bytes are served by L1 / L2 / Infinity Cache - and is
+    flagged `cache_served`: it is not a fraction of anything.  For the stress scene (3.3 GB tree) it is the figure
+    that the memory-side traffic is to be compared with;
+  * `valu_busy`: VALU issue cycles of the kernel's instructions over the SIMDs' cycles, once with every instruction
+    at the hardware's floor of 2 cycles and once priced by kind (2 / 4 / 8 cycles: tools/probes/valu_rate.hip,
+    profiles/valu_issue_cost.txt; classes from the SQ_INSTS_VALU_* counters, the rest at the mean cost of such
+    instructions in the kernel's ISA, profiles/valu_issue_mix.json): the truth lies between the two;
+  * `waits`: the share of wave-cycles spent waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) and waves per SIMD.
+`bound` says what the evidence says: the kernel runs at the hardware's maximum of 8 waves per SIMD with neither HBM nor
+the VALU port saturated - it is bound by the latency of the dependent round trips of a traversal step.
+The counters are collected by THIS run: before the parent process touches the GPU it runs `rocprofv3 --pmc` four times
+(one counter group each, no tracing) over a child that renders one frame of the same workload; if that fails, or with
+more than one rank, the per-ray figures of the committed profile of the same scene are replayed, tagged with their source.
 `cpu_baseline` times the CPU checker (oracle/, compiled -O3 -march=native for this host) on bounded samples of the
 same workload on this box's host cores; it is a reported baseline, nothing else.
 """
@@ -61,7 +63,8 @@ ISSUE_COST = {"SQ_INSTS_VALU_FMA_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_IN
               "SQ_INSTS_VALU_CVT": 4.0, "SQ_INSTS_VALU_TRANS_F32": 8.0}
 
 PMC_PASSES = [
-    ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE"]),
+    ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAIT_ANY",
+            "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]),   # 8 SQ counters: the most one pass can hold
     ("mix", ["SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_CVT",
              "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_SALU"]),
     ("fetch", ["FETCH_SIZE", "TCC_HIT_sum"]),       # FETCH_SIZE takes 3 of the 4 TCC slots
@@ -163,7 +166,7 @@ def build_native_oracle(log):
     return None
 
 
-def make_scene(scenes, name, W, H):
+def make_scene(scenes, name, W, H, materials="mixed"):
     if name == "dragonChrome":
         return scenes.dragon("chrome", res=(W, H))
     if name == "dragonGlass":
@@ -172,6 +175,8 @@ def make_scene(scenes, name, W, H):
         return scenes.dragon("milk", res=(W, H))
     if name == "fog":
         return scenes.fog(res=(W, H))
+    if name == "stress":
+        return scenes.stress(res=(W, H), materials=materials)
     return scenes.cornell(res=(W, H))
 
 
@@ -182,8 +187,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel PER GPU and step (weak scaling)")
     ap.add_argument("--total-spp", type=int, default=None, help="samples per pixel of the whole image, sharded over the GPUs (strong scaling)")
-    ap.add_argument("--res", type=str, default="1920x1080")
-    ap.add_argument("--scene", type=str, default="dragonChrome", choices=["dragonChrome", "dragonGlass", "dragonMilk", "cornell", "fog"])
+    ap.add_argument("--res", type=str, default=None, help="default 1920x1080 (stress: 3840x2160)")
+    ap.add_argument("--scene", type=str, default="dragonChrome", choices=["dragonChrome", "dragonGlass", "dragonMilk", "cornell", "fog", "stress"])
+    ap.add_argument("--materials", type=str, default="mixed", choices=["mixed", "opaque"],
+                    help="stress scene: diffuse / mirror / glass / milk cycling, or diffuse / mirror only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (replay the committed profile)")
@@ -195,6 +202,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.res is None:
+        args.res = "3840x2160" if args.scene == "stress" else "1920x1080"
     W, H = (int(x) for x in args.res.lower().split("x"))
 
     # work per rank
@@ -204,7 +213,7 @@ def main():
     if args.spp is None and args.total_spp is None:
         # one GPU: the single-GPU configuration (256 spp; a 1024-spp image is four such steps at the same rate);
         # more: the target's 1024-spp image, spp / N per GPU
-        args.total_spp = 256 if world == 1 else 1024
+        args.total_spp = (8 if args.scene == "stress" else 256) if world == 1 else 1024
     if args.total_spp is not None:
         total_spp = args.total_spp
         begin, count = distributed.sample_range(total_spp, rank, world)
@@ -223,7 +232,7 @@ def main():
         # Counter passes first: the children need the GPU's memory, and this process has not touched the GPU yet
         # (it only starts other programs before it does).
         try:
-            child = ["--res", args.res, "--scene", args.scene, "--spp", str(count)]
+            child = ["--res", args.res, "--scene", args.scene, "--materials", args.materials, "--spp", str(count)]
             pmc = collect_pmc(child, log)
             pmc_source = "rocprofv3 --pmc passes of this run (one frame of the same workload each)"
         except Exception as e:  # noqa: BLE001
@@ -263,7 +272,7 @@ def main():
             dist.reduce(x, dst=0, op=dist.ReduceOp.SUM)
 
     from pathtracer_amd import renderer, scenes
-    sc = make_scene(scenes, args.scene, W, H)
+    sc = make_scene(scenes, args.scene, W, H, args.materials)
     t0 = time.time()
     content = renderer.wa_content(sc, device=dev.index)
     build_s = time.time() - t0
@@ -326,7 +335,7 @@ def main():
         dt, rays = float(tmax[0]), float(t[1])
     paths = float(W) * H * total_spp * args.steps
     out = {
-        "metric": "Mpaths/s (whole job) " + args.scene + " 1080p; Mrays/s alongside",
+        "metric": "Mpaths/s (whole job) " + args.scene + (" 1080p" if (W, H) == (1920, 1080) else f" {W}x{H}") + "; Mrays/s alongside",
         "value": paths / dt / 1e6,
         "unit": "Mpaths/s",
         "n_gpus": world,
@@ -337,12 +346,15 @@ def main():
         "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (procedural 871200-triangle dragon stand-in in the bundled Cornell box)",
+        "data": "synthetic (procedural 871200-triangle dragon stand-in in the bundled Cornell box"
+                + ("; 64 transformed copies of it flattened into one soup)" if args.scene == "stress" else ")"),
         "mrays_per_s": rays / dt / 1e6,
         "rays_per_path": rays / paths,
         "config": {"workload": f"{args.scene} {W}x{H}, {work}, hsamples 1, lsamples 1, td {sc.td}",
                    "triangles": int(info.n_tris), "bvh_nodes": int(info.n_nodes), "bvh_bytes": int(info.node_bytes + info.tri_bytes),
-                   "parallelism": f"spp-sharded x{world}, one RCCL reduce per frame", "scene_build_s": round(build_s, 2)},
+                   "parallelism": f"spp-sharded x{world}, one RCCL reduce per frame", "scene_build_s": round(build_s, 2),
+                   "queue_bytes": int(st.queue_bytes), "queue_tasks_per_depth": int(st.queue_tasks),
+                   "queue_budget_gb": os.environ.get("WAPT_QUEUE_BUDGET_GB")},
     }
 
     if want_roofline:
@@ -375,82 +387,104 @@ def main():
         grays_kernel = rays_per_launch / (avg_ms * 1e-3) / 1e9
         algorithmic_gbs = bytes_per_ray * grays_kernel
 
+        pmc_rays = None
+        scene_tag = f"{args.scene}{'/' + args.materials if args.scene == 'stress' else ''} {W}x{H}"
         if pmc is None:
-            # replay of the committed counter summary of the round, tagged with where it comes from
+            # replay of the committed counter summary of the same scene, tagged with where it comes from (a run with
+            # more than one rank collects no counters: the per-ray figures of the kernel do not depend on the rank count)
             pf = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pf):
                 try:
                     pj = json.load(open(pf))
-                    if pj.get("workload") == out["config"]["workload"]:
+                    if pj.get("scene") == scene_tag:
                         pmc = pj["kernels"]
-                        pmc_source = f"replayed from profiles/pmc_latest.json @{pj.get('commit')} (counters were not collected in this run)"
+                        pmc_rays = pj.get("trace_rays")
+                        pmc_source = f"replayed from profiles/pmc_latest.json @{pj.get('commit')} ({pj.get('workload')}); counters were not collected in this run"
                 except Exception as e:  # noqa: BLE001
                     log.append(f"committed counter summary unreadable: {e}")
+        else:
+            pmc_rays = n_rays   # the counter passes rendered this very frame
 
-        roof = {"bound": "valu", "kernel": "k_trace (closest hit, one ray per lane)",
-                "achieved": None, "peak": VALU_PEAK_GCYCLES, "unit": "G VALU issue cycles/s", "frac": None,
-                "peak_definition": "1024 SIMDs x 2.4 GHz; a wave64 instruction takes 2, 4 or 8 issue cycles by kind "
-                                   "(tools/probes/valu_rate.hip, profiles/valu_issue_cost.txt)",
-                "traffic": None, "counter_source": pmc_source,
+        alg = {"bytes_per_ray": bytes_per_ray, "gbs": algorithmic_gbs, "ratio_to_hbm_peak": algorithmic_gbs / HBM_PEAK_GBS,
+               "ratio_to_l2_peak": algorithmic_gbs / L2_PEAK_GBS, "node_visits_per_ray": nodes_per_ray, "tri_tests_per_ray": tris_per_ray,
+               "cache_served": bool(algorithmic_gbs > HBM_PEAK_GBS),
+               "note": "32 B ray + 8 B hit + node and triangle records visited; above the HBM peak the bytes come from L1 / L2 / Infinity "
+                       "Cache and the ratio is not a fraction of anything"}
+        roof = {"bound": "latency of the dependent round trips of a traversal step at the hardware's maximum of 8 waves per SIMD "
+                         "(neither HBM nor VALU issue saturated)",
+                "kernel": "k_trace (closest hit, one ray per lane)",
+                "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "frac_definition": "memory-side bytes of the kernel (FETCH_SIZE + WRITE_SIZE counters) / its launch time (HIP events) / 8 TB/s",
+                "counter_source": pmc_source,
                 "rays_per_launch": rays_per_launch, "avg_launch_ms": avg_ms, "launches_per_step": int(n_launch),
                 "grays_per_s_in_kernel": grays_kernel,
-                "bytes_per_ray": bytes_per_ray, "node_visits_per_ray": nodes_per_ray, "tri_tests_per_ray": tris_per_ray,
-                "algorithmic_gbs": algorithmic_gbs, "algorithmic_frac_of_l2_peak": algorithmic_gbs / L2_PEAK_GBS,
-                "algorithmic_frac_of_hbm_peak": algorithmic_gbs / HBM_PEAK_GBS,
-                "note": "algorithmic bytes are served by L2 / Infinity Cache (52 MB tree), hence a rate above the HBM peak; "
-                        "the kernel is priced against VALU issue",
+                "algorithmic": alg,
                 "kernel_ms_per_step": fam_ms, "lane_utilisation": util,
                 "shadow_rays_per_step": int(shadow_rays), "probe_rays_per_step": int(st.n_probe_rays)}
         if pmc:
             kt = pmc.get("k_trace", {})
-            if kt.get("SQ_INSTS_VALU") and n_rays:
-                ipr = kt["SQ_INSTS_VALU"] / float(n_rays)   # wave-instructions of the frame's launches / its rays
-                cyc, how = issue_cycles(kt, "k_trace")
-                roof["valu_insts_per_ray"] = ipr
-                roof["valu_issue_cycles_per_ray"] = cyc / float(n_rays)
-                roof["valu_issue_mix"] = how
-                roof["achieved"] = roof["valu_issue_cycles_per_ray"] * grays_kernel
-                roof["frac"] = roof["achieved"] / VALU_PEAK_GCYCLES
-                roof["insts_frac_at_2_cycles"] = ipr * grays_kernel / VALU_PEAK_GINST
-                if kt.get("GRBM_GUI_ACTIVE") and ms_trace:
-                    # the counter sums the 8 XCDs; over the kernel's time it gives the clock the launch really ran at
-                    roof["clock_ghz_measured"] = kt["GRBM_GUI_ACTIVE"] / 8.0 / (ms_trace * 1e-3) / 1e9
-                    roof["frac_at_measured_clock"] = roof["achieved"] / (SIMDS * roof["clock_ghz_measured"])
-            if "FETCH_SIZE" in kt and "WRITE_SIZE" in kt:
-                nl = max(kt.get("launches", n_launch), 1)
-                f_raw, w = kt["FETCH_SIZE"] * 1024.0 / nl, kt["WRITE_SIZE"] * 1024.0 / nl   # the counters are in KiB
+            rays_c = float(pmc_rays or 0)   # closest-hit rays of the frame(s) the counters cover
+            if "FETCH_SIZE" in kt and "WRITE_SIZE" in kt and rays_c:
+                f_raw, w = kt["FETCH_SIZE"] * 1024.0, kt["WRITE_SIZE"] * 1024.0   # the counters are in KiB; sums over the frame's launches
+                bpr, bpr_x2 = (f_raw + w) / rays_c, (2.0 * f_raw + w) / rays_c
+                # bytes per ray from the counters x this run's rays per launch and launch time
+                roof["traffic_bytes_per_ray"] = bpr
+                roof["traffic"] = bpr * rays_per_launch
+                roof["achieved"] = bpr * grays_kernel
+                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
                 # raw FETCH_SIZE: the factor 2 that gfx950 needs for wide coalesced streaming reads is not calibrated for
                 # this kernel's 16-byte gathers; the doubled figure is kept beside it as the upper bound
-                roof["traffic"] = f_raw + w
-                roof["traffic_fetch_x2"] = 2.0 * f_raw + w
-                roof["traffic_gbs"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9
-                roof["traffic_frac_of_hbm_peak"] = roof["traffic_gbs"] / HBM_PEAK_GBS
-                roof["traffic_bytes_per_ray"] = roof["traffic"] / max(rays_per_launch, 1)
+                roof["traffic_fetch_x2"] = bpr_x2 * rays_per_launch
+                roof["frac_fetch_x2"] = bpr_x2 * grays_kernel / HBM_PEAK_GBS
+                roof["traffic_over_algorithmic"] = bpr / bytes_per_ray
                 if kt.get("TCC_HIT_sum") is not None and kt.get("TCC_MISS_sum") is not None:
                     roof["l2_hit_rate"] = kt["TCC_HIT_sum"] / max(kt["TCC_HIT_sum"] + kt["TCC_MISS_sum"], 1.0)
+            if kt.get("SQ_INSTS_VALU") and rays_c:
+                ipr = kt["SQ_INSTS_VALU"] / rays_c   # wave-instructions of the frame's launches / its rays
+                cyc, how = issue_cycles(kt, "k_trace")
+                vb = {"valu_insts_per_ray": ipr, "issue_cycles_per_ray_priced": cyc / rays_c, "issue_mix": how,
+                      "at_2_cycle_floor": ipr * grays_kernel / VALU_PEAK_GINST,
+                      "priced_by_kind": cyc / rays_c * grays_kernel / VALU_PEAK_GCYCLES,
+                      "peak_definition": "1024 SIMDs x 2.4 GHz; a wave64 instruction takes 2, 4 or 8 issue cycles by kind "
+                                         "(tools/probes/valu_rate.hip, profiles/valu_issue_cost.txt)"}
+                if pmc_rays == n_rays and kt.get("GRBM_GUI_ACTIVE") and ms_trace:
+                    # the counter sums the 8 XCDs; over the kernel's time it gives the clock the launch really ran at
+                    vb["clock_ghz_measured"] = kt["GRBM_GUI_ACTIVE"] / 8.0 / (ms_trace * 1e-3) / 1e9
+                roof["valu_busy"] = vb
+            if kt.get("SQ_WAVE_CYCLES") and kt.get("SQ_WAIT_ANY") is not None:
+                roof["waits"] = {"wait_any_frac": kt["SQ_WAIT_ANY"] / kt["SQ_WAVE_CYCLES"],
+                                 "wait_inst_frac": (kt.get("SQ_WAIT_INST_ANY") or 0.0) / kt["SQ_WAVE_CYCLES"],
+                                 "active_inst_frac": (kt.get("SQ_ACTIVE_INST_ANY") or 0.0) / kt["SQ_WAVE_CYCLES"],
+                                 "waves_per_simd": 8, "vgprs": 64,
+                                 "note": "share of the waves' resident cycles spent waiting on anything / waiting to issue / issuing"}
             # the whole frame: memory-side bytes of every kernel of the step over the step's time
             per_kernel, raw_sum, x2_sum = {}, 0.0, 0.0
+            scale = (n_rays / rays_c) if rays_c else 1.0   # (a replayed profile of another spp count, scaled to this frame)
             for fam, c in sorted(pmc.items()):
                 if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or not fam.startswith("k_"):
                     continue
-                f_raw, w = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
+                f_raw, w = c["FETCH_SIZE"] * 1024.0 * scale, c["WRITE_SIZE"] * 1024.0 * scale
                 per_kernel[fam] = {"fetch_raw_gb": f_raw / 1e9, "write_gb": w / 1e9, "launches": c.get("launches"),
                                    "valu_insts": c.get("SQ_INSTS_VALU")}
                 fam_key = {"k_trace": "trace", "k_surface": "shade", "k_shadow": "shadow", "k_probe": "probe", "k_volume": "volume"}.get(fam)
                 cyc_f, _ = issue_cycles(c, fam)
                 if fam_key and cyc_f and fam_ms.get(fam_key):
-                    per_kernel[fam]["valu_issue_frac"] = cyc_f / (fam_ms[fam_key] * 1e-3) / 1e9 / VALU_PEAK_GCYCLES
+                    per_kernel[fam]["valu_issue_frac"] = cyc_f * scale / (fam_ms[fam_key] * 1e-3) / 1e9 / VALU_PEAK_GCYCLES
+                    per_kernel[fam]["hbm_gbs_raw"] = (f_raw + w) / (fam_ms[fam_key] * 1e-3) / 1e9
+                if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_ANY") is not None:
+                    per_kernel[fam]["wait_any_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
                 raw_sum += f_raw + w
                 x2_sum += 2.0 * f_raw + w
-            step_s = out["ms_per_step"] * 1e-3
+            step_s = sum(v for v in fam_ms.values() if v) * 1e-3   # kernel time of a frame on one GPU
             roof["frame"] = {"hbm_gb_raw": raw_sum / 1e9, "hbm_gb_fetch_x2": x2_sum / 1e9,
                              "frame_hbm_gbs_raw": raw_sum / step_s / 1e9, "frame_hbm_gbs": x2_sum / step_s / 1e9,
+                             "frame_hbm_frac_raw": raw_sum / step_s / 1e9 / HBM_PEAK_GBS,
                              "frame_hbm_frac": x2_sum / step_s / 1e9 / HBM_PEAK_GBS, "kernels": per_kernel,
                              "note": "queue reads and writes are 16-byte-per-lane streams, for which FETCH_SIZE reads half the bytes on "
                                      "gfx950: frame_hbm_gbs doubles FETCH_SIZE (upper bound where the reads are BVH gathers), _raw does not"}
         out["roofline"] = roof
         if args.dump_pmc and pmc and pmc_source and pmc_source.startswith("rocprofv3"):
-            json.dump({"workload": out["config"]["workload"], "commit": git_sha(), "kernels": pmc,
+            json.dump({"scene": scene_tag, "workload": out["config"]["workload"], "commit": git_sha(), "trace_rays": int(n_rays), "kernels": pmc,
                        "units": "sums over the launches of one frame; FETCH_SIZE and WRITE_SIZE in KiB"},
                       open(args.dump_pmc, "w"), indent=1)
 

@@ -148,6 +148,9 @@ typedef struct wapt_stats {
     uint64_t n_probe_rays;
     /* profile bit 1: the five tallies for the probe searches */
     uint64_t probe_node_visits, probe_tri_tests, probe_wave_steps, probe_node_steps, probe_tri_trips;
+    /* device memory held by the scene's work queues after this call (their size follows the call's work, the free
+     * memory and WAPT_QUEUE_BUDGET_GB), and the tasks per depth that one closest-hit launch can take */
+    uint64_t queue_bytes, queue_tasks;
 } wapt_stats;
 
 typedef struct wapt_ray {

@@ -48,7 +48,8 @@ class Stats(C.Structure):
                 ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64), ("shadow_wave_steps", C.c_uint64),
                 ("shadow_node_steps", C.c_uint64), ("shadow_tri_trips", C.c_uint64),
                 ("queries_decided", C.c_uint64), ("n_probe_rays", C.c_uint64), ("probe_node_visits", C.c_uint64), ("probe_tri_tests", C.c_uint64),
-                ("probe_wave_steps", C.c_uint64), ("probe_node_steps", C.c_uint64), ("probe_tri_trips", C.c_uint64)]
+                ("probe_wave_steps", C.c_uint64), ("probe_node_steps", C.c_uint64), ("probe_tri_trips", C.c_uint64),
+                ("queue_bytes", C.c_uint64), ("queue_tasks", C.c_uint64)]
 
 
 class Ray(C.Structure):

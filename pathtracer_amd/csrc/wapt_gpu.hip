@@ -1044,7 +1044,11 @@ __device__ __forceinline__ void wave_add_rgb(float* sum, float4* stage, bool pre
         const float r = wave_total_f(maj ? c.x : 0.f), g = wave_total_f(maj ? c.y : 0.f), b = wave_total_f(maj ? c.z : 0.f);
         if (lane < 3u) {
             const float v = lane == 0u ? r : lane == 1u ? g : b;
+#ifdef WAPT_EXP_NOATOMIC
+            asm volatile("" ::"v"(v));
+#else
             if (v != 0.f) unsafeAtomicAdd(sum + (size_t)px0 * 3 + lane, v);
+#endif
         }
         pred = pred && !maj;
         m = __ballot(pred);
@@ -2580,6 +2584,8 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         stats->probe_wave_steps = h_rays[18];
         stats->probe_node_steps = h_rays[19];
         stats->probe_tri_trips = h_rays[20];
+        stats->queue_bytes = s->queue_bytes;
+        stats->queue_tasks = s->capR;
         if (tm.on) {
             double ms[FAM_N] = {0};
             for (auto& r : tm.recs) {
