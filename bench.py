@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dump-pmc", type=str, default=None, help="write the counters collected by this run to FILE (the committed profile)")
     ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--dump-image", type=str, default=None, help="rank 0 writes the last timed frame (mean radiance, H x W x 3 float32) to FILE.npy")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -333,6 +334,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, rays = float(tmax[0]), float(t[1])
+    if rank == 0 and args.dump_image:
+        np.save(args.dump_image, image.reshape(H, W, 3).cpu().numpy())
     paths = float(W) * H * total_spp * args.steps
     out = {
         "metric": "Mpaths/s (whole job) " + args.scene + (" 1080p" if (W, H) == (1920, 1080) else f" {W}x{H}") + "; Mrays/s alongside",

@@ -2143,12 +2143,12 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, const FanOut& f0, int l
         capR = env_u32("WAPT_RAD_CAP", 1u << 29);
         capR = (uint32_t)std::min<uint64_t>(capR, paths_r * std::max<uint64_t>(f0.kids, 1));
         capR = std::max(capR, 64u * 64u) & ~63u;
-        capS = env_u32("WAPT_SHADOW_CAP", capR * (uint32_t)std::max(1, std::min(s->n_lights, 4)));
-        auto footprint = [&](uint64_t r, uint64_t sh) { return (uint64_t)depths * r * 48 + sh * 48 + r * 8; };
-        while (footprint(capR, capS) > budget && (capR > (1u << 16) || capS > (1u << 20))) {
-            if (capR > (1u << 16)) capR >>= 1;
-            if (capS > (1u << 20)) capS >>= 1;
-        }
+        // cut to the budget: R per depth, the shadow queue (one entry per task and light, four lights' worth at most)
+        // and the hit records
+        const uint64_t per_light = (uint64_t)std::max(1, std::min(s->n_lights, 4));
+        const uint64_t per_task = (uint64_t)depths * 48 + per_light * 48 + 8;
+        if ((uint64_t)capR * per_task > budget) capR = std::max<uint32_t>((uint32_t)(budget / per_task) & ~63u, 64u * 64u);
+        capS = env_u32("WAPT_SHADOW_CAP", (uint32_t)std::min<uint64_t>((uint64_t)capR * per_light, 0xfffff000u));
         capSA = capS;
         capP = capM = 64u;
         capG = capR;
