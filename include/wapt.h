@@ -245,10 +245,13 @@ int wapt_intersect_device(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wap
                           wapt_trace_counters* counters, float* ms);
 
 /* No counterpart in the reference.  wapt_intersect_device for callers that cannot allocate device memory
- * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same closest-hit
- * batch, with the launch's work-feed counters, result counters and traversal-stack spill area in a 32 MiB array
- * that is part of the library's code object (one copy per GPU, held until the process ends) instead of memory
- * the library allocates.  Calls no hipMalloc / hipFree.  At most 2^30 rays per call (WAPT_E_LIMIT beyond); a tree
+ * (tight serving loops, harnesses that forbid hipMalloc, code that runs while another stream of the process is
+ * under HIP graph capture, where allocation calls are forbidden): the same closest-hit batch, with the launch's
+ * work-feed counters, result counters and traversal-stack spill area in a 32 MiB array that is part of the
+ * library's code object (one copy per GPU, held until the process ends) instead of memory the library allocates.
+ * Calls no hipMalloc / hipFree.  The call is NOT itself capturable: it runs at once on the scene's own stream,
+ * copies its overflow counter back and blocks until the batch is done; d_rays must be complete before the call
+ * (it is not ordered after work on the caller's streams).  At most 2^30 rays per call (WAPT_E_LIMIT beyond); a tree
  * deeper than the spill area holds at full width runs with fewer blocks.  All calls on one GPU share that GPU's
  * array, whatever scene they use: calls that overlap on one GPU race. */
 int wapt_intersect_device_static(wapt_scene* s, const wapt_ray* d_rays, uint32_t n, wapt_hit* d_hits);

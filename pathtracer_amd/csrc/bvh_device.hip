@@ -624,7 +624,9 @@ bool bvh8_build_device(const float* verts, const int32_t* obj, const int32_t* pr
                 *err = "clustering made no progress";
                 return false;
             }
-            stalled = (m - m_new) < m / 256u && m > 1024u;
+            // (small lists too: a run of nested or growing boxes merges one pair per round and builds a chain as deep as
+            //  the list is long - the rule for them is "less than a sixteenth merged")
+            stalled = m > 1024u ? (m - m_new) < m / 256u : (m > 16u && (m - m_new) * 16u < m);
             if (getenv("WAPT_PLOC_VERBOSE")) fprintf(stderr, "ploc round %d: %u -> %u clusters%s\n", rounds, m, m_new, stalled ? " (stalled)" : "");
             m = m_new;
         }

@@ -386,6 +386,35 @@ __global__ void k_light_tris(const float4* tris, uint32_t n_tris, int n_lights, 
     if (k == 1) lights[obj].tri1 = (int)i;
 }
 
+// DLight::front_clear for the area lights (set to 1 by the host beforehand): cleared if a triangle of another object
+// comes within `reach` of the light's quad without staying on or behind the quad's plane (see wapt_scene_create).
+// One thread per triangle of the tree.
+__global__ void k_front_clear(const float4* tris, uint32_t n_tris, int n_lights, DLight* lights, double reach) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tris) return;
+    const float4 a = tris[(size_t)i * 3], b = tris[(size_t)i * 3 + 1], c = tris[(size_t)i * 3 + 2];
+    const int obj = (int)__float_as_uint(c.y);
+    const float v[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
+    for (int l = 0; l < n_lights; l++) {
+        const DLight& L = lights[l];
+        if (L.type != 0 || l == obj || !L.front_clear) continue;
+        bool overlap = true;
+        for (int ax = 0; ax < 3 && overlap; ax++) {
+            const double q[4] = {L.P[ax], (double)L.P[ax] + L.U[ax], (double)L.P[ax] + L.V[ax], (double)L.P[ax] + L.U[ax] + L.V[ax]};
+            const double lo = fmin(fmin(q[0], q[1]), fmin(q[2], q[3])) - reach, hi = fmax(fmax(q[0], q[1]), fmax(q[2], q[3])) + reach;
+            const double tlo = fmin(fmin((double)v[ax], (double)v[3 + ax]), (double)v[6 + ax]);
+            const double thi = fmax(fmax((double)v[ax], (double)v[3 + ax]), (double)v[6 + ax]);
+            overlap = tlo <= hi && thi >= lo;
+        }
+        if (!overlap) continue;
+        for (int k = 0; k < 3; k++) {
+            const double sd = ((double)v[3 * k] - L.P[0]) * L.N[0] + ((double)v[3 * k + 1] - L.P[1]) * L.N[1] +
+                              ((double)v[3 * k + 2] - L.P[2]) * L.N[2];
+            if (!(sd <= 2.5e-4)) atomicExch(&lights[l].front_clear, 0);
+        }
+    }
+}
+
 // Between two slices of a step's march samples: the feeds of the shadow and probe kernels start over, and
 // (shadows_too) the shadow queue, once its kernel has run.
 __global__ void k_reset_sp(uint32_t* cnt, int shadows_too) {
@@ -1773,6 +1802,7 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return wapt_fail(WAPT_E_NO_DEVICE, "no HIP device: this library has no CPU path");
     if (device < 0 || device >= ndev) return wapt_fail(WAPT_E_INVALID, "device index out of range");
+    bool fallback_to_host = false;  // the builder was not asked for by name: a device build that fails may be redone on the host
     if (builder == WAPT_BUILDER_AUTO) {
         // The device builder (locally-ordered clustering over the Morton order) is the default at every size: its trees
         // trace as fast as or faster than the host's binned-SAH trees (dragonChrome +4 %, dragonGlass +2 %, Cornell +2 %;
@@ -1780,7 +1810,10 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
         const char* e = getenv("WAPT_BVH_BUILDER");
         if (e && !strcmp(e, "host")) builder = WAPT_BUILDER_HOST_SAH;
         else if (e && !strcmp(e, "device")) builder = WAPT_BUILDER_DEVICE_LBVH;
-        else builder = desc->n_tris >= (uint64_t)env_u32("WAPT_DEVICE_BUILD_MIN_TRIS", 1u) ? WAPT_BUILDER_DEVICE_LBVH : WAPT_BUILDER_HOST_SAH;
+        else {
+            builder = desc->n_tris >= (uint64_t)env_u32("WAPT_DEVICE_BUILD_MIN_TRIS", 1u) ? WAPT_BUILDER_DEVICE_LBVH : WAPT_BUILDER_HOST_SAH;
+            fallback_to_host = builder == WAPT_BUILDER_DEVICE_LBVH;
+        }
     }
 
     HIPCHK(hipSetDevice(device));
@@ -1806,20 +1839,33 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
         for (int i = 0; i < desc->n_objects; i++) opaque[i] = (uint8_t)tri_flags_of(desc->materials[i].flags);
         DeviceBvh8 db;
         std::string berr;
-        if (!bvh8_build_device(desc->tri_verts, desc->tri_obj, desc->tri_prim, desc->n_tris, opaque.data(),
-                               (uint32_t)desc->n_objects, s->stream, &db, &berr))
-            return bail(wapt_fail(WAPT_E_INVALID, "device BVH build: " + berr));
-        s->d_nodes = db.d_nodes;
-        s->d_tris = db.d_tris;
-        s->n_nodes = db.n_nodes;
-        s->n_tris = db.n_tris;
-        s->bvh_depth = db.max_depth;
-        s->sah = db.sah_cost;
-        memcpy(blo, db.lo, 12);
-        memcpy(bhi, db.hi, 12);
-        if (s->bvh_depth > WAPT_STACK_CAP)
-            return bail(wapt_fail(WAPT_E_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(s->bvh_depth) + ")"));
-    } else {
+        const bool built = bvh8_build_device(desc->tri_verts, desc->tri_obj, desc->tri_prim, desc->n_tris, opaque.data(),
+                                             (uint32_t)desc->n_objects, s->stream, &db, &berr);
+        if (built) {
+            s->d_nodes = db.d_nodes;
+            s->d_tris = db.d_tris;
+            s->n_nodes = db.n_nodes;
+            s->n_tris = db.n_tris;
+            s->bvh_depth = db.max_depth;
+            s->sah = db.sah_cost;
+            memcpy(blo, db.lo, 12);
+            memcpy(bhi, db.hi, 12);
+        }
+        if (!built || s->bvh_depth > WAPT_STACK_CAP) {
+            // The device builder gave up (clustering stalled, tree too deep to collapse, out of device memory) or its tree
+            // is deeper than the traversal stack.  A caller who named the builder gets the error; the default choice
+            // falls back to the host's binned-SAH builder, which handles such inputs.
+            const std::string why = built ? "tree deeper than the traversal stack (" + std::to_string(s->bvh_depth) + ")" : berr;
+            if (!fallback_to_host)
+                return bail(wapt_fail(built ? WAPT_E_LIMIT : WAPT_E_INVALID, "device BVH build: " + why));
+            (void)hipFree(s->d_nodes);
+            (void)hipFree(s->d_tris);
+            s->d_nodes = s->d_tris = nullptr;
+            if (getenv("WAPT_BVH_VERBOSE")) fprintf(stderr, "wapt: device BVH build failed (%s): building on the host\n", why.c_str());
+            builder = WAPT_BUILDER_HOST_SAH;
+        }
+    }
+    if (builder == WAPT_BUILDER_HOST_SAH) {
         Bvh8 bvh;
         const char* err = nullptr;
         if (!bvh8_build(desc->tri_verts, desc->tri_obj, desc->tri_prim, desc->n_tris, &bvh, &err))
@@ -1867,7 +1913,6 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
         }
     }
     s->builder = builder;
-    s->build_seconds = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
 
     std::vector<DMaterial> mats((size_t)desc->n_objects + 1);
     for (int i = 0; i < desc->n_objects; i++) mats[i] = to_device(desc->materials[i]);
@@ -1927,39 +1972,19 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     // the front (lights.cpp:91 rejects the rest) at |cos| >= 0.25, so a surface that stays on or behind the quad's plane
     // (to within 2.5e-4: TRACE_BIAS x 0.25) is met after B or with it, which counts as arrived (cpp:775).  The light is
     // clear if every other object's triangle near the quad (boxes within the margin) is such a surface.
+    // (the test itself runs on the GPU over the tree's triangle records, below: k_front_clear)
+    const double fc_reach = 0.002 + 1e-4 * (double)s->max_segment + 1e-3;
+    bool fc_test = false;
     {
-        const double reach = 0.002 + 1e-4 * (double)s->max_segment + 1e-3;
         const uint64_t budget = 4000000000ull;  // triangle-light pairs looked at (a scene with thousands of lights skips this)
         int n_area = 0;
         for (int i = 0; i < desc->n_lights; i++) n_area += desc->lights[i].type == 0;
         const char* cut_env = getenv("WAPT_SHADOW_CUT");  // WAPT_SHADOW_CUT=0: every walk searches up to its end point
         if (n_area > 0 && (uint64_t)n_area * desc->n_tris <= budget && !(cut_env && cut_env[0] == '0')) {
+            fc_test = true;
             for (int l = 0; l < desc->n_lights; l++) {
-                if (desc->lights[l].type != 0) continue;
                 const DLight& L = lights[l];
-                double lo[3], hi[3];
-                for (int a = 0; a < 3; a++) {
-                    const double c[4] = {L.P[a], (double)L.P[a] + L.U[a], (double)L.P[a] + L.V[a], (double)L.P[a] + L.U[a] + L.V[a]};
-                    lo[a] = std::min(std::min(c[0], c[1]), std::min(c[2], c[3])) - reach;
-                    hi[a] = std::max(std::max(c[0], c[1]), std::max(c[2], c[3])) + reach;
-                }
-                bool clear = std::isfinite(L.N[0]) && std::isfinite(L.N[1]) && std::isfinite(L.N[2]);
-                for (uint64_t t = 0; t < desc->n_tris && clear; t++) {
-                    if (desc->tri_obj[t] == l) continue;
-                    const float* v = desc->tri_verts + 9 * t;
-                    bool overlap = true;
-                    for (int a = 0; a < 3 && overlap; a++) {
-                        const double tlo = std::min(std::min(v[a], v[3 + a]), v[6 + a]), thi = std::max(std::max(v[a], v[3 + a]), v[6 + a]);
-                        overlap = tlo <= hi[a] && thi >= lo[a];
-                    }
-                    if (!overlap) continue;
-                    for (int k = 0; k < 3 && clear; k++) {
-                        const double sd = ((double)v[3 * k] - L.P[0]) * L.N[0] + ((double)v[3 * k + 1] - L.P[1]) * L.N[1] +
-                                          ((double)v[3 * k + 2] - L.P[2]) * L.N[2];
-                        if (!(sd <= 2.5e-4)) clear = false;
-                    }
-                }
-                lights[l].front_clear = clear ? 1 : 0;
+                lights[l].front_clear = (L.type == 0 && std::isfinite(L.N[0]) && std::isfinite(L.N[1]) && std::isfinite(L.N[2])) ? 1 : 0;
             }
         }
     }
@@ -1969,6 +1994,9 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     if (desc->n_lights > 0)
         hipLaunchKernelGGL(k_light_tris, dim3((unsigned)((s->n_tris + 255) / 256)), dim3(256), 0, s->stream, (const float4*)s->d_tris,
                            (uint32_t)s->n_tris, desc->n_lights, (DLight*)s->d_lights);
+    if (desc->n_lights > 0 && fc_test)
+        hipLaunchKernelGGL(k_front_clear, dim3((unsigned)((s->n_tris + 255) / 256)), dim3(256), 0, s->stream, (const float4*)s->d_tris,
+                           (uint32_t)s->n_tris, desc->n_lights, (DLight*)s->d_lights, fc_reach);
     // DLight::probe_slot: the lights that a probe ray can have as its closest hit (those with triangles in the tree;
     // all of them when WAPT_GENERAL_PROBE=1 asks for plain searches), numbered in order
     if (desc->n_lights > 0) {
@@ -1983,7 +2011,8 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     HIPCHK_S(hipGetDeviceProperties(&prop, device));
     uint32_t cus = (uint32_t)std::max(prop.multiProcessorCount, 1);
     s->cus = cus;
-    s->grid = cus * env_u32("WAPT_BLOCKS_PER_CU", 8);
+    // (never fewer blocks than work-feed shards: the groups of a shard that no block maps to would never be drawn)
+    s->grid = std::max<uint32_t>(cus * env_u32("WAPT_BLOCKS_PER_CU", 8), WAPT_FEED_SHARDS);
     s->sgrid = std::max(1u, cus * env_u32("WAPT_SBLOCKS_PER_CU", 2) * (1024u / WAPT_SBLOCK));  // blocks of the shading kernels
     HIPCHK_S(hipMalloc((void**)&s->d_cnt, CNT_TOTAL * sizeof(uint32_t)));
     HIPCHK_S(hipMemset(s->d_cnt, 0, CNT_TOTAL * sizeof(uint32_t)));
@@ -2021,6 +2050,8 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     s->ks.wr = desc->world_radius;
     memset(&s->kq, 0, sizeof(s->kq));
     HIPCHK_S(hipDeviceSynchronize());
+    // (tree, upload, and the tests of the lights against the tree's triangles)
+    s->build_seconds = (float)std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
     *out = holder.release();
     return WAPT_OK;
 #undef HIPCHK_S
@@ -2945,7 +2976,11 @@ static int intersect_device_static(wapt_scene* s, const wapt_ray* d_rays, uint32
     depth_slots = std::min(depth_slots, WAPT_STACK_CAP - WAPT_LDS_STACK);
     const size_t spill_bytes = WAPT_STATIC_SCRATCH_BYTES - WAPT_STATIC_HEADER_BYTES;
     const uint32_t blocks = (uint32_t)std::min<size_t>(s->grid, spill_bytes / ((size_t)depth_slots * sizeof(uint2) * WAPT_BLOCK));
-    if (blocks == 0) return wapt_fail(WAPT_E_LIMIT, "BVH too deep for the static scratch array");
+    // (a launch with fewer blocks than work-feed shards would leave the groups of the unmapped shards undrawn)
+    static_assert((WAPT_STATIC_SCRATCH_BYTES - WAPT_STATIC_HEADER_BYTES) / ((size_t)(WAPT_STACK_CAP - WAPT_LDS_STACK) * sizeof(uint2) * WAPT_BLOCK) >=
+                      WAPT_FEED_SHARDS,
+                  "the static scratch array must hold the stack spill area of at least one block per work-feed shard");
+    if (blocks < WAPT_FEED_SHARDS) return wapt_fail(WAPT_E_LIMIT, "BVH too deep for the static scratch array");
     TraceMem tm = s->ks.tm;
     tm.spill = (uint2*)(base + WAPT_STATIC_HEADER_BYTES);
     tm.spill_stride = blocks * WAPT_BLOCK;
