@@ -321,14 +321,14 @@ struct CollapseOut {
 __global__ void k_collapse(Tree2 T, const uint32_t* __restrict__ refs, uint32_t n_refs, uint32_t level_start,
                            uint32_t* __restrict__ next_refs, CollapseOut out, const float* __restrict__ verts,
                            const int32_t* __restrict__ obj, const int32_t* __restrict__ prim, const uint8_t* __restrict__ opaque,
-                           float root_area, uint32_t* __restrict__ fail) {
+                           float root_area, uint32_t* __restrict__ fail, uint32_t leaf_max) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_refs) return;
     const uint32_t me = refs[i];
     uint32_t ch[8];
     Box6 cbx[8];
     int nch = 0;
-    if (ref_count(T, me) <= 3u) {
+    if (ref_count(T, me) <= leaf_max) {
         ch[nch++] = me;  // the whole tree is one leaf
     } else {
         ch[nch++] = T.left[me];
@@ -338,7 +338,7 @@ __global__ void k_collapse(Tree2 T, const uint32_t* __restrict__ refs, uint32_t 
             int bi = -1;
             float ba = -1.f;
             for (int k = 0; k < nch; k++) {
-                if (ref_count(T, ch[k]) > 3u) {
+                if (ref_count(T, ch[k]) > leaf_max) {
                     float a = box_area(cbx[k]);
                     if (a > ba) {
                         ba = a;
@@ -415,7 +415,7 @@ __global__ void k_collapse(Tree2 T, const uint32_t* __restrict__ refs, uint32_t 
     uint32_t n_inner = 0, n_tri = 0;
     for (int k = 0; k < nch; k++) {
         uint32_t c = ref_count(T, ch[k]);
-        if (c > 3u) n_inner++;
+        if (c > leaf_max) n_inner++;
         else n_tri += c;
     }
     uint32_t base = n_inner ? atomicAdd(out.node_counter, n_inner) : 0u;
@@ -453,7 +453,7 @@ __global__ void k_collapse(Tree2 T, const uint32_t* __restrict__ refs, uint32_t 
             qhi[a][s] = (uint8_t)qh;
         }
         uint32_t c = ref_count(T, ch[k]);
-        if (c > 3u) {
+        if (c > leaf_max) {
             node.imask |= (uint8_t)(1u << s);
             node.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
             next_refs[base - (level_start + n_refs) + inner_k] = ch[k];
@@ -624,9 +624,11 @@ bool bvh8_build_device(const float* verts, const int32_t* obj, const int32_t* pr
                 *err = "clustering made no progress";
                 return false;
             }
-            // (small lists too: a run of nested or growing boxes merges one pair per round and builds a chain as deep as
-            //  the list is long - the rule for them is "less than a sixteenth merged")
-            stalled = m > 1024u ? (m - m_new) < m / 256u : (m > 16u && (m - m_new) * 16u < m);
+            // (shorter lists too, down to 64 clusters: a run of nested or growing boxes merges one pair per round and builds
+            //  a chain as deep as the list is long.  The bar stays far below what an ordinary round removes - 15-40 % -
+            //  because pairing by position costs tree quality: with "less than a sixteenth" for short lists the last
+            //  rounds of every build were paired that way and dragonChrome's rays visited 40 % more nodes)
+            stalled = m > 1024u ? (m - m_new) < m / 256u : (m > 64u && (m - m_new) * 64u < m);
             if (getenv("WAPT_PLOC_VERBOSE")) fprintf(stderr, "ploc round %d: %u -> %u clusters%s\n", rounds, m, m_new, stalled ? " (stalled)" : "");
             m = m_new;
         }
@@ -649,6 +651,9 @@ bool bvh8_build_device(const float* verts, const int32_t* obj, const int32_t* pr
     }
 
     // 5. collapse, one level per launch
+    // (a subtree of at most leaf_max triangles becomes a leaf; WAPT_DEVICE_LEAF_MAX = 1..3 for experiments)
+    uint32_t leaf_max = 3u;
+    if (const char* e = getenv("WAPT_DEVICE_LEAF_MAX")) leaf_max = (uint32_t)std::min(3, std::max(1, atoi(e)));
     const uint32_t node_cap = std::max(n, 2u);  // every wide node is a distinct inner node of the binary tree
     Bvh8Node* d_nodes = nullptr;
     Bvh8Tri* d_tris = nullptr;
@@ -676,7 +681,7 @@ bool bvh8_build_device(const float* verts, const int32_t* obj, const int32_t* pr
         depth++;
         if (depth > 64) return fail("binary tree too deep to collapse");
         hipLaunchKernelGGL(k_collapse, dim3((level_count + 127) / 128), dim3(128), 0, st, T, cur, level_count, level_start, nxt, co,
-                           d_verts, d_obj, d_prim, d_opaque, root_area, d_counters + 2);
+                           d_verts, d_obj, d_prim, d_opaque, root_area, d_counters + 2, leaf_max);
         if (hipMemcpyAsync(h_counters, d_counters, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
             return fail(std::string("collapse: ") + hipGetErrorString(hipGetLastError()));

@@ -1048,7 +1048,6 @@ __global__ __launch_bounds__(WAPT_VOLBLOCK, INSIDE ? WAPT_VOLUME_WAVES_IN : WAPT
 __device__ __forceinline__ uint32_t vol_sample_of(const KQueues& q, uint32_t rel) {
     return rel - udiv_by(rel, q.vol_div_m, q.vol_div_k) * q.vol_ms;
 }
-
 // Adds the colours of the lanes with `pred` to their pixels' sums.  The red, green and blue of one pixel
 // go out from three neighbouring lanes: float atomics are carried out at the memory side, one request per
 // 64-byte segment that a wave instruction touches, so this takes one request per pixel where one atomic

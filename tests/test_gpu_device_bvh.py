@@ -39,6 +39,10 @@ def test_device_tree_gives_the_same_hits(make):
     dt = np.abs(hd["t"] - hh["t"]) <= 1e-5 * np.abs(hh["t"])
     print("nodes", info_d.n_nodes, info_h.n_nodes, "depth", info_d.max_depth, info_h.max_depth, "sah", info_d.sah_cost,
           info_h.sah_cost, "same", same.mean())
+    # tree quality: the clustering build's surface-area cost stays near the binned-SAH tree's (dragon stand-in: 9.2 against
+    # 9.2; a build whose last rounds paired clusters by position instead of by merged area measured 40 % more node visits)
+    if info_h.n_tris > 10_000:
+        assert info_d.sah_cost <= 1.08 * info_h.sah_cost, (info_d.sah_cost, info_h.sah_cost)
     assert (same | dt).mean() >= 0.9999     # a different triangle only where two are hit at the same distance
     assert dt.mean() >= 0.9999
     o = oracle_api.OracleScene(sc)
