@@ -40,6 +40,8 @@
 // Last word of a triangle record: flags of its object in the low byte, the object index above.
 #define WAPT_TRI_OPAQUE 1u   // the object is opaque: a shadow walk that meets it before its end point is over
 #define WAPT_TRI_PLAIN 2u    // opaque, clear inside and no dielectric: reaching it AT the end point changes nothing
+#define WAPT_TRI_GLASS 4u    // a dielectric with ior > 1: a shadow walk that ENTERS it (meets a front face) is over
+                             // (src/unidirectionalPathTracer.cpp:757-759: glass casts opaque shadows)
 #define WAPT_TRI_OBJ_SHIFT 8
 
 struct TraceMem {
@@ -277,7 +279,15 @@ __device__ __forceinline__ void tri_phase_coop(const TraceMem& m, Trav& t, bool 
             float U = dot(R, e2) * sgn;
             float V = dot(R, e1) * sgn;
             float Tn = dot(Ng, Cv) * sgn;
-            if (den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * tmin < Tn && Tn <= absDen * tmax) {
+            // ANY: only what ends a walk counts - opaque surfaces, and front faces (den < 0: Ng is the geometric normal)
+            // of glass; back faces of glass and dielectrics with ior <= 1 are passed through as if they were not there
+            // (the scenes that use this form have nothing but such objects: clear inside, no attenuation either side)
+            bool counts = true;
+            if (ANY) {
+                const uint32_t fl = __float_as_uint(c.w);
+                counts = (fl & WAPT_TRI_OPAQUE) != 0u || ((fl & WAPT_TRI_GLASS) != 0u && den < 0.f);
+            }
+            if (counts && den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen && absDen * tmin < Tn && Tn <= absDen * tmax) {
                 // search distance only (the final one is re-evaluated in fp64, see refine_distance): the 1-ulp
                 // reciprocal saves the ten-instruction IEEE division
                 if (ANY && Tn < absDen * tblock) {
@@ -447,7 +457,7 @@ __device__ __forceinline__ bool trav_step(const TraceMem& m, Trav& t, bool have,
                 t.hit = ti;
                 if (SHADOW) {
                     t.hflag = __float_as_uint(c.w);
-                    if ((t.hflag & WAPT_TRI_OPAQUE) && Tn < absDen * t.tblock) {
+                    if (((t.hflag & WAPT_TRI_OPAQUE) || ((t.hflag & WAPT_TRI_GLASS) && den < 0.f)) && Tn < absDen * t.tblock) {
                         t.G = make_uint2(0u, 0u);
                         t.sp = 0;
                         bits = 0u;

@@ -1236,6 +1236,11 @@ __global__ __launch_bounds__(WAPT_BLOCK, PLAIN ? WAPT_SHADOW_WAVES : WAPT_SHADOW
                         if (!(tmax > ABl + (0.002f + 5e-5f * ABl))) tmax = refine_distance(sc.tm.tris, tri, t.o, t.d, WAPT_TRACE_BIAS, tmax);
                         const float dd = mag(point_at(t.o, tmax, t.d) - t.o);
                         lit = dd >= ABl - WAPT_TRACE_BIAS;
+                        // (a front face of glass ends the walk even within TRACE_BIAS of B, and a little beyond: the
+                        //  reference looks at the material, cpp:757-759, before it asks whether B is reached, cpp:775)
+                        if (!FOGGY && lit && dd <= ABl + WAPT_TRACE_BIAS &&
+                            (__float_as_uint(sc.tm.tris[(size_t)tri * 3 + 2].w) & WAPT_TRI_GLASS) != 0u)
+                            lit = false;
                         blocked = !lit;
                         if (FOGGY && lit && dd <= ABl + WAPT_TRACE_BIAS) {
                             int obj, prim;
@@ -1771,13 +1776,23 @@ int validate_desc(const wapt_scene_desc* d) {
 }  // namespace
 
 // Flag byte of a triangle record (traverse.h) from the flags of its object's material.
-static uint32_t tri_flags_of(uint32_t mf) {
+static uint32_t tri_flags_of(const wapt_material& m) {
+    const uint32_t mf = m.flags;
     uint32_t f = 0;
     if (mf & WAPT_MAT_OPAQUE) {
         f |= WAPT_TRI_OPAQUE;
         if ((mf & WAPT_MAT_CLEAR) && !(mf & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS))) f |= WAPT_TRI_PLAIN;
     }
+    if ((mf & (WAPT_MAT_DIELECTRIC | WAPT_MAT_DIELECTRICSSS)) && m.ior > 1.0f) f |= WAPT_TRI_GLASS;
     return f;
+}
+// A shadow walk in a scene of such objects (under a clear global medium) is over with ONE search: the object is plain
+// (opaque, clear inside, no dielectric) or a dielectric that is not opaque and clear inside - nothing attenuates on
+// either side of its surface, its front faces end the walk if its ior is above 1 and are passed otherwise.
+static bool one_search_object(const wapt_material& m) {
+    if (tri_flags_of(m) & WAPT_TRI_PLAIN) return true;
+    if (!WAPT_SHADOW_COOP) return false;  // (only the cooperative any-hit phase leaves out the surfaces that are passed)
+    return (m.flags & WAPT_MAT_DIELECTRIC) && !(m.flags & WAPT_MAT_DIELECTRICSSS) && (m.flags & WAPT_MAT_CLEAR) && !(m.flags & WAPT_MAT_OPAQUE);
 }
 
 extern "C" int wapt_scene_create(const wapt_scene_desc* desc, int32_t device, wapt_scene** out) {
@@ -1835,7 +1850,7 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     float blo[3], bhi[3];
     if (builder == WAPT_BUILDER_DEVICE_LBVH) {
         std::vector<uint8_t> opaque((size_t)desc->n_objects);
-        for (int i = 0; i < desc->n_objects; i++) opaque[i] = (uint8_t)tri_flags_of(desc->materials[i].flags);
+        for (int i = 0; i < desc->n_objects; i++) opaque[i] = (uint8_t)tri_flags_of(desc->materials[i]);
         DeviceBvh8 db;
         std::string berr;
         const bool built = bvh8_build_device(desc->tri_verts, desc->tri_obj, desc->tri_prim, desc->n_tris, opaque.data(),
@@ -1878,7 +1893,7 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
         memcpy(blo, bvh.lo, 12);
         memcpy(bhi, bvh.hi, 12);
         // last word of a triangle record: what shadow walks need to know about its object without fetching the material
-        for (auto& T : bvh.tris) T.pad = tri_flags_of(desc->materials[T.obj].flags) | ((uint32_t)T.obj << WAPT_TRI_OBJ_SHIFT);
+        for (auto& T : bvh.tris) T.pad = tri_flags_of(desc->materials[T.obj]) | ((uint32_t)T.obj << WAPT_TRI_OBJ_SHIFT);
         HIPCHK_S(hipMalloc(&s->d_nodes, bvh.nodes.size() * sizeof(Bvh8Node)));
         HIPCHK_S(hipMalloc(&s->d_tris, bvh.tris.size() * sizeof(Bvh8Tri)));
         HIPCHK_S(hipMemcpy(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice));
@@ -2039,8 +2054,10 @@ static int scene_create_with(const wapt_scene_desc* desc, int32_t device, int32_
     // every object opaque, clear and no dielectric, the global medium clear: the one-search shadow kernel
     s->all_plain = s->ks.fast_shadow != 0 && (desc->global_medium.flags & WAPT_MAT_CLEAR) != 0;
     s->all_plain_foggy = s->ks.fast_shadow != 0 && (desc->global_medium.flags & WAPT_MAT_CLEAR) == 0;  // the same under a medium
-    for (int i = 0; i < desc->n_objects; i++)
-        if (!(tri_flags_of(desc->materials[i].flags) & WAPT_TRI_PLAIN)) s->all_plain = s->all_plain_foggy = false;
+    for (int i = 0; i < desc->n_objects; i++) {
+        if (!one_search_object(desc->materials[i])) s->all_plain = false;
+        if (!(tri_flags_of(desc->materials[i]) & WAPT_TRI_PLAIN)) s->all_plain_foggy = false;  // (a medium outside glass: the segments differ)
+    }
     // WAPT_GENERAL_PROBE=1: every probe ray gets the plain closest-hit search (the tests compare the two)
     s->ks.fast_probe = env_u32("WAPT_GENERAL_PROBE", 0) ? 0 : 1;
     s->ks.cam = to_device(desc->camera);

@@ -192,7 +192,8 @@ def test_shadow_walk_shortcuts_equal_the_general_path(name, monkeypatch):
     """Shadow walks that the kernel finishes from registers (opaque surface before the end point, clear miss, hit on
     the sampled light's own quad) against the same walks sent through the step-by-step path of visibility()
     (WAPT_GENERAL_SHADOW=1, read at scene creation): same image up to the order of the float atomics, same number
-    of closest-hit queries."""
+    of closest-hit queries.  The glass scene's walks are one search each as well (front faces of glass end a walk, back
+    faces are passed, cpp:757-759)."""
     sc, spp, kw = {
         "cornell_spheres": (scenes.cornell(res=(96, 96), spheres=True, sphere_segments=(16, 32)), 16, dict(hsamples=2, lsamples=2)),
         "dragon_chrome": (scenes.dragon("chrome", res=(128, 72), n_along=200, n_around=60), 16, {}),
@@ -203,7 +204,12 @@ def test_shadow_walk_shortcuts_equal_the_general_path(name, monkeypatch):
     monkeypatch.setenv("WAPT_GENERAL_SHADOW", "1")
     general, st_gen = gpu_render(sc, spp, seed=3, **kw)
     np.testing.assert_allclose(fast, general, rtol=2e-4, atol=1e-6)
-    assert st_fast.rays == st_gen.rays
+    if name == "dragon_glass":
+        # a walk that starts INSIDE the glass (floor points under the dragon) passes a back face first: the step-by-step
+        # path searches once per segment, the one-search kernel passes such faces inside its single search
+        assert 0 <= st_gen.rays - st_fast.rays <= 1e-4 * st_gen.rays
+    else:
+        assert st_fast.rays == st_gen.rays
 
 
 def _open_milk_sheet_scene(res=(32, 32)):
