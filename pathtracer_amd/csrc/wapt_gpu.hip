@@ -978,9 +978,8 @@ __global__ __launch_bounds__(WAPT_VOLBLOCK, INSIDE ? WAPT_VOLUME_WAVES_IN : WAPT
                 atomicAdd(&q.cnt[CNT_QOVERFLOW], 1u);
             } else {
                 const size_t k = (size_t)(depth + 1) * q.capR + slot;
-                if (cemit) {
+                if (cemit) {  // (plane A of the child is the sample's origin record, written above: see the host's choice of VO)
                     const V3 cbeta = ((4.0f * WAPT_PI) / pV) * cs;
-                    VSTORE(&q.RA[k], make_float4(S.x, S.y, S.z, u2f(pixel)));
                     VSTORE(&q.RB[k], make_float4(cdir.x, cdir.y, cdir.z, u2f(make_info(depth + 1, false, RAY_CAMERA, medium))));
                     VSTORE(&q.RC[k], make_float4(cbeta.x, cbeta.y, cbeta.z, u2f(wapt_key_child(key, WAPT_SLOT_VOL | (uint32_t)s))));
                 } else {
@@ -2503,8 +2502,10 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
         });
         // the walks of the shadow queue: those the surface kernel sent and, beyond the first s1 entries, `vol_count` entries
         // of the march samples of the current slice (vol_ms samples, or 0: no such entries, the queue counter says it all)
+        float4* vo_now = q.VO;  // origin records of the slice of march samples whose walks are in the shadow queue
         auto run_shadow = [&](uint32_t s1, uint32_t vol_ms, uint32_t vol_count) {
             KQueues qs = q;
+            if (vol_ms) qs.VO = vo_now;
             qs.vol_s1 = s1;
             qs.vol_ms = vol_ms;
             qs.vol_scount = vol_count;
@@ -2566,6 +2567,10 @@ int render_accumulate_view(wapt_scene* s, const wapt_render_params* prm, float* 
                     qv.vol_scount = inside ? 0u : (uint32_t)(ms * sh_per);
                     qv.vol_pcount = (uint32_t)(ms * pr_per);
                     const uint32_t kid0 = d < td ? (uint32_t)(kids_now + (inside ? M_out : 0) + m0) : 0xffffffffu;
+                    // origin and pixel of a sample are plane A of its child task: where children exist the samples'
+                    // records ARE that plane of R[d + 1] (kids_now + M <= capR was checked above), written once
+                    if (d < td) qv.VO = q.RA + (size_t)(d + 1) * s->capR + kid0;
+                    vo_now = qv.VO;
                     tm.run(FAM_VOLUME, [&] {
                         if (inside) hipLaunchKernelGGL(k_volume<true>, volgrid, volblock, 0, st, ks, qv, kp, d, (uint32_t)m0, (uint32_t)ms, kid0, ks.lights);
                         else hipLaunchKernelGGL(k_volume<false>, volgrid, volblock, 0, st, ks, qv, kp, d, (uint32_t)m0, (uint32_t)ms, kid0, ks.lights);
