@@ -64,7 +64,8 @@ struct KQueues {
     float4 *RA, *RB, *RC;    // radiance tasks, depth d at [d*capR, (d+1)*capR)
     float4 *SA, *SB, *SC;
     float4 *PB, *PC;
-    float4* VO;              // origin | pixel of the march samples of the current launch of the march kernel
+    float4* VO;              // origin | pixel of the march samples of the current launch of the march kernel; where the
+                             // samples have children it points into RA: the record is plane A of the sample's child
     uint2* hits;             // (t bits, triangle) per task of the current step
     // the marched segments of the current step (scenes with media), written by the surface kernel:
     // A.xyz | length, unit direction | pV, beta.rgb | key, pixel | medium+1, doVol<<30, inside<<31 | march samples | stream
