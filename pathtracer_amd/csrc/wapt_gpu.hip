@@ -718,10 +718,12 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                 }
             }
         }
-        if (MEDIA) {
-            // the segment goes on the list of the march kernel with everything that kernel needs to know about it
-            uint32_t sv = block_push(&q.cnt[CNT_QV], toV);
-            if (toV) {
+        constexpr bool MERGE = ONE && WAPT_SURFACE_MERGE;
+        // the segment goes on the list of the march kernel with everything that kernel needs to know about it
+        // (MERGE, scenes with lights: the list's slot is reserved below, together with the first light's shadow walk and the child)
+        const bool qv_merged = MEDIA && MERGE && sc.n_lights > 0;
+        auto write_segment = [&](uint32_t sv) {
+            {
                 const Segment g = march_segment(sc, p, c, depth);
                 const bool inside_ok = g.inside && g.medium >= 0;  // (the global medium has no surface of its own to look for)
                 q.G0[sv] = make_float4(g.A.x, g.A.y, g.A.z, g.len);
@@ -730,6 +732,10 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                 q.G3[sv] = make_float4(u2f(c.pixel), u2f((uint32_t)(g.medium + 1) | ((uint32_t)g.doVol << 29) | ((uint32_t)g.inside << 30) | ((uint32_t)inside_ok << 31)),
                                        u2f((uint32_t)g.rms), u2f(c.stream));
             }
+        };
+        if (MEDIA && !qv_merged) {
+            const uint32_t sv = block_push(&q.cnt[CNT_QV], toV);
+            if (toV) write_segment(sv);
         }
         const bool lambert = kind == LAMBERT;
         const bool deeper = lambert && (depth + 1 <= p.td);
@@ -738,7 +744,6 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
         // of barriers around an atomic whose answer the whole block waits for) per task instead of two.
         __shared__ float4 s_child[WAPT_SURFACE_MERGE ? 2 * WAPT_SBLOCK : 1];
         bool child_emit = false;
-        constexpr bool MERGE = ONE && WAPT_SURFACE_MERGE;
         if (MERGE) {
             V3 dir = cdir, b = cb;
             uint32_t info = cinfo, key = ckey;
@@ -783,10 +788,11 @@ __global__ __launch_bounds__(WAPT_SBLOCK, WAPT_SURFACE_WAVES) void k_surface(KSc
                     DBG(c.pixel, "nee d=%d key=%08x emit=%d LP=(%.5f %.5f %.5f) wt=%g\n", depth, c.key, (int)emit, LP.x, LP.y, LP.z, wt.x);
                 }
                 if (MERGE && l == 0) {
-                    uint32_t* const counters[3] = {&q.cnt[CNT_S], &q.cnt[CNT_R(depth + 1)], &q.cnt[CNT_R(depth + 1)]};
-                    const bool preds[3] = {emit && !is_zero(wt), child_emit, false};
+                    uint32_t* const counters[3] = {&q.cnt[CNT_S], &q.cnt[CNT_R(depth + 1)], MEDIA ? &q.cnt[CNT_QV] : &q.cnt[CNT_R(depth + 1)]};
+                    const bool preds[3] = {emit && !is_zero(wt), child_emit, MEDIA && toV};
                     uint32_t slots[3];
                     block_push3(counters, preds, slots);
+                    if (MEDIA && toV) write_segment(slots[2]);
                     if (preds[0]) write_shadow(q, slots[0], c.P, Wi, Wl, wt, c.pixel, tgt);
                     if (preds[1]) {
                         const float4 cd = s_child[threadIdx.x], cbk = s_child[WAPT_SBLOCK + threadIdx.x];
