@@ -69,6 +69,9 @@ __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 #ifndef WAPT_VOLBLOCK
 #define WAPT_VOLBLOCK 256
 #endif
+#ifndef WAPT_FAST_ATTENUATION
+#define WAPT_FAST_ATTENUATION 1
+#endif
 #ifndef WAPT_PROBE_WAVES
 #define WAPT_PROBE_WAVES 7
 #endif
@@ -211,6 +214,21 @@ __device__ __forceinline__ V3 attenuation(const DMaterial& m, float dist) {
     return vexp(v3(-m.st[0] * dist, -m.st[1] * dist, -m.st[2] * dist));
 }
 
+// exp(a) where the result only multiplies a contribution (never decides anything): the hardware's 2^x on a * log2(e),
+// good to about 1e-6 relative for the arguments of an attenuation, in 2 instructions instead of the library's 12
+__device__ __forceinline__ V3 vexp_mul(V3 a) {
+#if WAPT_FAST_ATTENUATION
+    return v3(__expf(a.x), __expf(a.y), __expf(a.z));
+#else
+    return vexp(a);
+#endif
+}
+// volumeAttenuation where the result is a factor of a contribution only
+__device__ __forceinline__ V3 attenuation_mul(const DMaterial& m, float dist) {
+    if (m.flags & WAPT_MAT_CLEAR) return v3(1.f, 1.f, 1.f);
+    return vexp_mul(v3(-m.st[0] * dist, -m.st[1] * dist, -m.st[2] * dist));
+}
+
 __device__ __forceinline__ bool finite_dir(V3 d) {
     float l = dot(d, d);
     return l > 0.25f && l < 4.0f;  // false for NaN
@@ -351,7 +369,7 @@ __device__ __forceinline__ V3 surface_weight(const DMaterial* __restrict__ mats,
         V3 st = gst;
         if (med >= 0) st = ld3(mats[med].st);
         const float dist = mag(c.P - c.o);
-        w = w * vexp(v3(-st.x * dist, -st.y * dist, -st.z * dist));
+        w = w * vexp_mul(v3(-st.x * dist, -st.y * dist, -st.z * dist));
     }
     return (1.0f / p_surface(info_depth(c.info))) * w;
 }
@@ -972,7 +990,7 @@ __global__ __launch_bounds__(WAPT_VOLBLOCK, INSIDE ? WAPT_VOLUME_WAVES_IN : WAPT
         }
         const V3 S = A + x * IBn;
         // common factor of everything gathered at S (cpp:611-612) times the scattering albedo and phase
-        const V3 cs = (rpdf_x * rrms * WAPT_PHASE) * (beta * vexp(v3(-st.x * x, -st.y * x, -st.z * x)) * ss);
+        const V3 cs = (rpdf_x * rrms * WAPT_PHASE) * (beta * vexp_mul(v3(-st.x * x, -st.y * x, -st.z * x)) * ss);
         VSTORE(&q.VO[jj], make_float4(S.x, S.y, S.z, u2f(pixel)));
         // (iii) indirect: one uniform direction, no emission at the next hit (cpp:587-609)
         if (kid0 != 0xffffffffu) {
@@ -1233,7 +1251,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, PLAIN ? WAPT_SHADOW_WAVES : WAPT_SHADOW
             if (PLAIN && cut) {
                 lit = !blocked && tri == 0xffffffffu;
                 blocked = !lit;
-                if (FOGGY && lit) V = gclear ? v3(1.f, 1.f, 1.f) : vexp(v3(-gst.x * ABl, -gst.y * ABl, -gst.z * ABl));
+                if (FOGGY && lit) V = gclear ? v3(1.f, 1.f, 1.f) : vexp_mul(v3(-gst.x * ABl, -gst.y * ABl, -gst.z * ABl));
             } else if (PLAIN) {
                 if (!blocked) {
                     bool at_target = false;
@@ -1270,7 +1288,7 @@ __global__ __launch_bounds__(WAPT_BLOCK, PLAIN ? WAPT_SHADOW_WAVES : WAPT_SHADOW
                             seg = dot(t.d, N) < 0.0f ? dd : 0.0f;
                         }
                     }
-                    if (FOGGY && lit && seg > 0.0f) V = gclear ? v3(1.f, 1.f, 1.f) : vexp(v3(-gst.x * seg, -gst.y * seg, -gst.z * seg));
+                    if (FOGGY && lit && seg > 0.0f) V = gclear ? v3(1.f, 1.f, 1.f) : vexp_mul(v3(-gst.x * seg, -gst.y * seg, -gst.z * seg));
                 }
             } else if (!blocked) {
                 const bool in_clear = gclear && cur == global_m;
@@ -1502,13 +1520,13 @@ __global__ __launch_bounds__(WAPT_BLOCK, WAPT_PROBE_WAVES) void k_probe(KScene s
                 V3 hp = point_at(S, tmax, dir);
                 if (stage == 1) {
                     if (obj == light) {
-                        V3 att = attenuation(sc.mats[sc.n_objects], mag(hp - S)) * attenuation(M, seg0);
+                        V3 att = attenuation_mul(sc.mats[sc.n_objects], mag(hp - S)) * attenuation_mul(M, seg0);
                         contrib = (1.0f - F0) * (w * ld3(L.Li) * att);
                         lit = true;
                     }
                 } else if (kind == 0) {
                     if (obj == light) {
-                        V3 att = attenuation(M, mag(hp - S));
+                        V3 att = attenuation_mul(M, mag(hp - S));
                         float alt = light_pdf(L, hp, S);
                         float mis = WAPT_MIS_CONST / (WAPT_MIS_CONST + alt);
                         if (mis != mis) mis = 1.0f;
