@@ -223,6 +223,14 @@ __device__ __forceinline__ V3 vexp_mul(V3 a) {
     return vexp(a);
 #endif
 }
+// 1 / x to an ulp, for factors of contributions
+__device__ __forceinline__ float fast_rcp(float x) {
+#if WAPT_FAST_ATTENUATION
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
 // volumeAttenuation where the result is a factor of a contribution only
 __device__ __forceinline__ V3 attenuation_mul(const DMaterial& m, float dist) {
     if (m.flags & WAPT_MAT_CLEAR) return v3(1.f, 1.f, 1.f);
@@ -975,7 +983,7 @@ __global__ __launch_bounds__(WAPT_VOLBLOCK, INSIDE ? WAPT_VOLUME_WAVES_IN : WAPT
         const bool doVol = (gw >> 29) & 1u, inside = (gw >> 30) & 1u;
         const DMaterial& M = medium_of(sc, medium);
         const V3 ss = ld3(M.ss), st = ld3(M.st);
-        const float rrms = rms > 0 ? 1.0f / (float)rms : 0.f;
+        const float rrms = rms > 0 ? fast_rcp((float)rms) : 0.f;
         float x, rpdf_x;
         {
             const float u = wapt_rand(stream, WAPT_DIM_MARCH + (uint32_t)s);
@@ -1003,7 +1011,7 @@ __global__ __launch_bounds__(WAPT_VOLBLOCK, INSIDE ? WAPT_VOLUME_WAVES_IN : WAPT
             } else {
                 const size_t k = (size_t)(depth + 1) * q.capR + slot;
                 if (cemit) {  // (plane A of the child is the sample's origin record, written above: see the host's choice of VO)
-                    const V3 cbeta = ((4.0f * WAPT_PI) / pV) * cs;
+                    const V3 cbeta = ((4.0f * WAPT_PI) * fast_rcp(pV)) * cs;
                     VSTORE(&q.RB[k], make_float4(cdir.x, cdir.y, cdir.z, u2f(make_info(depth + 1, false, RAY_CAMERA, medium))));
                     VSTORE(&q.RC[k], make_float4(cbeta.x, cbeta.y, cbeta.z, u2f(wapt_key_child(key, WAPT_SLOT_VOL | (uint32_t)s))));
                 } else {
@@ -1023,9 +1031,8 @@ __global__ __launch_bounds__(WAPT_VOLBLOCK, INSIDE ? WAPT_VOLUME_WAVES_IN : WAPT
                         const uint32_t dim = WAPT_DIM_VNEE + 2u * (uint32_t)((s * sc.n_lights + l) * p.lsamples + k);
                         float rpdf;
                         if (light_sample(L, S, v3(0, 0, 0), false, wapt_rand(stream, dim), wapt_rand(stream, dim + 1), &LP, &rpdf)) {
-                            float pdf = 1.0f / rpdf;
-                            float mis = pdf / (pdf + WAPT_MIS_CONST);
-                            if (rpdf == 0.0f) mis = 1.0f;
+                            // pdf / (pdf + c) with pdf = 1 / rpdf (cpp:500-503; 1 for rpdf = 0, as there), a factor only
+                            const float mis = fast_rcp(1.0f + WAPT_MIS_CONST * rpdf);
                             wt = (rpdf * mis * rls) * (cs * ld3(L.Li));
                             emit = !is_zero(wt);
                         }
