@@ -379,7 +379,11 @@ __device__ __forceinline__ V3 surface_weight(const DMaterial* __restrict__ mats,
         const float dist = mag(c.P - c.o);
         w = w * vexp_mul(v3(-st.x * dist, -st.y * dist, -st.z * dist));
     }
+#if WAPT_FAST_FACTORS
+    return (0.125f * (float)info_depth(c.info) + 1.0f) * w;  // 1 / pS without its two divisions (a factor only)
+#else
     return (1.0f / p_surface(info_depth(c.info))) * w;
+#endif
 }
 
 #ifdef WAPT_DEBUG_PIXEL
