@@ -1003,7 +1003,8 @@ __global__ __launch_bounds__(WAPT_VOLBLOCK, INSIDE ? WAPT_VOLUME_WAVES_IN : WAPT
         const V3 S = A + x * IBn;
         // common factor of everything gathered at S (cpp:611-612) times the scattering albedo and phase
         const V3 cs = (rpdf_x * rrms * WAPT_PHASE) * (beta * vexp_mul(v3(-st.x * x, -st.y * x, -st.z * x)) * ss);
-        VSTORE(&q.VO[jj], make_float4(S.x, S.y, S.z, u2f(pixel)));
+        // (where the samples have children the record lies in R[depth + 1] itself, see the host: never beyond that queue)
+        if (kid0 == 0xffffffffu || kid0 + jj < q.capR) VSTORE(&q.VO[jj], make_float4(S.x, S.y, S.z, u2f(pixel)));
         // (iii) indirect: one uniform direction, no emission at the next hit (cpp:587-609)
         if (kid0 != 0xffffffffu) {
             const uint32_t dim = WAPT_DIM_VCHILD + 2u * (uint32_t)s;
