@@ -2233,7 +2233,10 @@ int ensure_queues(wapt_scene* s, int td, uint64_t paths, const FanOut& f0, int l
     int depths = td + 1;
     const uint64_t L = (uint64_t)std::max(s->n_lights, 0);
     const uint64_t paths_r = (paths + 4095) & ~(uint64_t)4095;
-    const uint64_t budget = queue_budget(s, nullptr);
+    // (64 KB of it set aside for the small fixed lists and the alignment of the blocks, so that the allocation stays
+    //  within what queue_budget() names)
+    const uint64_t budget_all = queue_budget(s, nullptr);
+    const uint64_t budget = budget_all > (1ull << 17) ? budget_all - (1ull << 16) : budget_all;
     auto cap32 = [](uint64_t v) { return (uint32_t)std::min<uint64_t>(v, 0x7ffff000u); };
     // capacities in entries: R per depth, S bodies, SA (origins of the surface kernel's walks), P bodies, march samples
     // of a step (QM, VO), segments / tasks of a step (G0-G3, hit records)

@@ -46,3 +46,24 @@ def test_media_scene_in_both_orders(monkeypatch):
     b, sb = _render(sc, 6, monkeypatch, {"WAPT_PIXEL_MAJOR": "1"})
     np.testing.assert_allclose(a, b, rtol=5e-4, atol=1e-5)
     assert int(sa.rays) + int(sa.queries_decided) == int(sb.rays) + int(sb.queries_decided)
+
+
+@pytest.mark.parametrize("name,spp,budget_gb", [("chrome", 16, "0.05"), ("glass", 8, "0.05"), ("milk", 4, "0.1"), ("fog", 2, "0.1")])
+def test_queue_memory_budget_changes_no_result(name, spp, budget_gb, monkeypatch):
+    """WAPT_QUEUE_BUDGET_GB bounds the memory of the work queues (the frame is then rendered in more, smaller steps): the
+    same samples, so the same image to the order of the float additions and the same number of closest-hit queries; the
+    allocation stays within the budget."""
+    sc = {"chrome": lambda: scenes.dragon("chrome", res=(320, 180), n_along=200, n_around=60),
+          "glass": lambda: scenes.dragon("glass", res=(320, 180), n_along=200, n_around=60, td=5),
+          "milk": lambda: scenes.dragon("milk", res=(160, 90), n_along=200, n_around=60),
+          "fog": lambda: scenes.fog(res=(160, 90))}[name]()
+    monkeypatch.delenv("WAPT_QUEUE_BUDGET_GB", raising=False)
+    ref, st0 = _render(sc, spp, monkeypatch, {})
+    fb, st = _render(sc, spp, monkeypatch, {"WAPT_QUEUE_BUDGET_GB": budget_gb})
+    assert np.isfinite(ref).all() and ref.mean() > 0
+    assert 0 < int(st.queue_bytes) <= float(budget_gb) * 1e9 and int(st.queue_bytes) < int(st0.queue_bytes)
+    assert int(st.rays) + int(st.queries_decided) == int(st0.rays) + int(st0.queries_decided)
+    assert st.stack_overflows == 0
+    ok = np.abs(fb - ref) <= 5e-4 * np.abs(ref) + 1e-5
+    assert ok.mean() >= 0.9999, ok.mean()
+    np.testing.assert_allclose(fb.mean((0, 1)), ref.mean((0, 1)), rtol=1e-4)
